@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Capture golden input/output vectors from the *reference* loss modules.
+
+Runs ONLY in the authoring container (needs /root/reference, which never
+travels to the GPU box).  It imports the reference's two loss files
+unmodified -- `NoBlankCTC.py` and `NoBlankBinaryCTC.py` -- with `.cuda()`
+made an identity (the container has no GPU; the files hard-code `.cuda()`,
+NoBlankCTC.py:40-96), runs forward + autograd backward on seeded inputs and
+stores inputs AND outputs as small .npz fixtures next to this script.
+
+The fixtures are data (inputs and expected outputs); no reference source text
+is stored.  Blank-CTC fixtures (F5) come from torch.nn.functional.ctc_loss on
+CPU, the third-party arithmetic behind models/layers/AsyncTFCriterion.py:198.
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py F1 F2      # a subset
+"""
+import os
+import sys
+import time
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("CTC_REFERENCE", "/root/reference")
+
+
+def _import_reference():
+    # .cuda() -> identity, tensors and modules alike (CPU-only container)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    from NoBlankCTC import NoBlankCTC  # noqa
+    from NoBlankBinaryCTC import NoBlankBinaryCTC  # noqa
+    return NoBlankCTC, NoBlankBinaryCTC
+
+
+def run_noblank(mod_cls, x, lab, in_len, tgt_len):
+    """-> (mean loss, per-sample nll, grad wrt x) from the reference module."""
+    xt = torch.tensor(x, dtype=torch.float32, requires_grad=True)
+    labt = torch.tensor(lab)
+    il = torch.tensor(in_len, dtype=torch.int64)
+    tl = torch.tensor(tgt_len, dtype=torch.int64)
+    m = mod_cls()
+    loss = m(xt, labt, il, tl)
+    loss.backward()
+    # per-sample nll: rerun each sample alone (mean over a batch of one)
+    nll = []
+    for b in range(x.shape[1]):
+        with torch.no_grad():
+            lb = mod_cls()(torch.tensor(x[:, b:b + 1]), labt[b:b + 1], il[b:b + 1], tl[b:b + 1])
+        nll.append(float(lb))
+    return (np.float32(loss.item()), np.asarray(nll, np.float32),
+            xt.grad.detach().numpy().astype(np.float32))
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+def synth_noblank(seed, T, B, C, S, var_T=True, int64=False):
+    """SURVEY 8(d) generator: randn logits, L in [1,S], -1 padded labels."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, B, C, generator=g)
+    L = torch.randint(1, S + 1, (B,), generator=g)
+    lab = torch.randint(0, C, (B, S), generator=g, dtype=torch.int32)
+    for b in range(B):
+        lab[b, int(L[b]):] = -1
+    if var_T:
+        lo = min(S, T)
+        Tb = torch.randint(lo, T + 1, (B,), generator=g)
+        Tb = torch.maximum(Tb, L)
+    else:
+        Tb = torch.full((B,), T, dtype=torch.int64)
+    if int64:
+        lab = lab.long()
+    return x.numpy(), lab.numpy(), Tb.numpy().astype(np.int64), L.numpy().astype(np.int64)
+
+
+def synth_binary(seed, T, B, C, S, var_T=True, density=0.05):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, B, C, generator=g)
+    L = torch.randint(1, S + 1, (B,), generator=g)
+    y = (torch.rand(B, S, C, generator=g) < density).float()
+    for b in range(B):
+        y[b, int(L[b]):] = 0.0   # pad rows 0: nn.BCELoss rejects -1
+    if var_T:
+        Tb = torch.maximum(torch.randint(min(S, T), T + 1, (B,), generator=g), L)
+    else:
+        Tb = torch.full((B,), T, dtype=torch.int64)
+    return x.numpy(), y.numpy(), Tb.numpy().astype(np.int64), L.numpy().astype(np.int64)
+
+
+# ---------------------------------------------------------------- fixtures
+def F1(NB, NBB):
+    """KAT-1/2/3: inputs embedded in the reference's test.py (:258-269, :384-397)."""
+    x2 = np.array([[[1.2, 2.3, 1.4, -0.5, 2.2], [-0.1, 1.2, 0.4, 2.5, 3.2]],
+                   [[0.5, 1.3, 2.2, 0.1, 2.4], [1.1, 2.2, 0.7, 1.4, 2.2]],
+                   [[0.8, -1.5, 2.3, 1.2, 2.1], [0.9, 1.4, 0.6, 2.3, 1.0]],
+                   [[0.2, -1.0, 1.3, 2.2, 0.1], [0.2, 1.0, 1.6, 1.3, 1.2]]], np.float32)
+    lab2 = np.array([[2, 3, 4], [1, 2, 0]], np.int64)
+    loss, nll, grad = run_noblank(NB, x2, lab2, [4, 4], [3, 2])
+    save("kat1_noblank", x=x2, lab=lab2, in_len=np.array([4, 4], np.int64),
+         tgt_len=np.array([3, 2], np.int64), loss=loss, nll=nll, grad=grad)
+    x1 = x2[:, :1].copy()
+    y1 = np.array([[[0, 0, 1, 0, 0], [0, 0, 0, 1, 0], [0, 0, 0, 0, 1]]], np.float32)
+    loss, nll, grad = run_noblank(NBB, x1, y1, [4], [3])
+    save("kat2_binary", x=x1, y=y1, in_len=np.array([4], np.int64),
+         tgt_len=np.array([3], np.int64), loss=loss, nll=nll, grad=grad)
+    loss, nll, grad = run_noblank(NB, x1, lab2[:1], [4], [3])
+    save("kat3_noblank", x=x1, lab=lab2[:1], in_len=np.array([4], np.int64),
+         tgt_len=np.array([3], np.int64), loss=loss, nll=nll, grad=grad)
+
+
+def F2(NB, NBB):
+    """config 1: B=4 T=20 C=10 S=5, variable T_b and L_b, -1 padded int32 labels."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(20, 4, 10, generator=g).numpy()
+    L = np.array([5, 3, 1, 4], np.int64)
+    Tb = np.array([20, 17, 20, 9], np.int64)
+    lab = torch.randint(0, 10, (4, 5), generator=g, dtype=torch.int32).numpy()
+    for b in range(4):
+        lab[b, L[b]:] = -1
+    loss, nll, grad = run_noblank(NB, x, lab, Tb, L)
+    save("cfg1_noblank", x=x, lab=lab, in_len=Tb, tgt_len=L, loss=loss, nll=nll, grad=grad)
+    xb, y, Tb2, L2 = synth_binary(1, 20, 4, 10, 5, density=0.3)
+    loss, nll, grad = run_noblank(NBB, xb, y, Tb2, L2)
+    save("cfg1_binary", x=xb, y=y, in_len=Tb2, tgt_len=L2, loss=loss, nll=nll, grad=grad)
+
+
+def F3(NB, NBB):
+    """Charades-shaped reduced batch: T=150 C=158 S=20 (B=4 each; ~10 s each)."""
+    x, lab, Tb, L = synth_noblank(2, 150, 4, 158, 20, var_T=True)
+    t0 = time.time()
+    loss, nll, grad = run_noblank(NB, x, lab, Tb, L)
+    print("  noblank T=150 B=4: %.1f s" % (time.time() - t0))
+    save("charades_noblank", x=x, lab=lab, in_len=Tb, tgt_len=L, loss=loss, nll=nll, grad=grad)
+    xb, y, Tb2, L2 = synth_binary(3, 150, 3, 158, 20, var_T=True)
+    t0 = time.time()
+    loss, nll, grad = run_noblank(NBB, xb, y, Tb2, L2)
+    print("  binary T=150 B=3: %.1f s" % (time.time() - t0))
+    save("charades_binary", x=xb, y=y, in_len=Tb2, tgt_len=L2, loss=loss, nll=nll, grad=grad)
+
+
+def F4(NB, NBB):
+    """edge set: repeated labels, L=1, L=S, T_b=L_b (single path), T_b<T, int64 labels."""
+    T, B, C, S = 12, 8, 7, 6
+    g = torch.Generator().manual_seed(4)
+    x = (2.0 * torch.randn(T, B, C, generator=g)).numpy()
+    lab = np.array([[0, 0, 2, 2, 2, 5],      # repeated consecutive labels, L=S
+                    [3, -1, -1, -1, -1, -1],  # L=1
+                    [6, 5, 4, 3, 2, 1],      # L=S, T_b=L_b: single feasible path
+                    [1, 2, 1, 2, -1, -1],    # alternating repeats
+                    [4, 4, 4, 4, 4, 4],      # all the same class
+                    [0, 1, -1, -1, -1, -1],
+                    [2, 6, 0, -1, -1, -1],
+                    [5, 5, 1, 0, 0, -1]], np.int64)
+    L = np.array([6, 1, 6, 4, 6, 2, 3, 5], np.int64)
+    Tb = np.array([12, 12, 6, 7, 12, 2, 3, 11], np.int64)
+    loss, nll, grad = run_noblank(NB, x, lab, Tb, L)
+    save("edge_noblank", x=x, lab=lab, in_len=Tb, tgt_len=L, loss=loss, nll=nll, grad=grad)
+    # binary edge: soft (non 0/1) targets, dense rows, empty rows, larger |x| (<=15)
+    gb = torch.Generator().manual_seed(5)
+    xb = (4.0 * torch.randn(T, 5, C, generator=gb)).clamp(-14, 14).numpy()
+    y = torch.rand(5, S, C, generator=gb)
+    y[0] = (y[0] < 0.5).float()
+    y[1] = 0.0
+    y[2] = 1.0
+    y = y.numpy()
+    Lb = np.array([6, 2, 6, 1, 4], np.int64)
+    Tbb = np.array([12, 5, 6, 12, 9], np.int64)
+    for b in range(5):
+        y[b, Lb[b]:] = 0.0
+    loss, nll, grad = run_noblank(NBB, xb, y, Tbb, Lb)
+    save("edge_binary", x=xb, y=y, in_len=Tbb, tgt_len=Lb, loss=loss, nll=nll, grad=grad)
+
+
+def F5(NB, NBB):
+    """blank-CTC: torch.nn.functional.ctc_loss(blank=0, reduction='mean'), CPU."""
+    import torch.nn.functional as Fn
+    for name, (T, B, C, S, seed) in {"blank_small": (50, 4, 20, 8, 6),
+                                     "blank_long": (400, 2, 100, 30, 7)}.items():
+        g = torch.Generator().manual_seed(seed)
+        lp = torch.randn(T, B, C, generator=g).log_softmax(2).requires_grad_(True)
+        tgt = torch.randint(1, C, (B, S), generator=g)
+        L = torch.randint(1, S + 1, (B,), generator=g)
+        Tb = torch.randint(2 * S + 1, T + 1, (B,), generator=g)
+        if name == "blank_small":
+            tgt[0, 1] = tgt[0, 0]; tgt[0, 2] = tgt[0, 0]   # repeats force blanks
+            L[0] = S
+            Tb[0] = T
+            L[1] = 1
+        loss = Fn.ctc_loss(lp, tgt, Tb, L, blank=0, reduction="mean", zero_infinity=False)
+        loss.backward()
+        nll = Fn.ctc_loss(lp.detach(), tgt, Tb, L, blank=0, reduction="none")
+        save(name, lp=lp.detach().numpy(), tgt=tgt.numpy(), in_len=Tb.numpy(), tgt_len=L.numpy(),
+             loss=np.float32(loss.item()), nll=nll.numpy(), grad=lp.grad.numpy())
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    NB, NBB = _import_reference()
+    which = sys.argv[1:] or ["F1", "F2", "F3", "F4", "F5"]
+    for w in which:
+        print(w)
+        globals()[w](NB, NBB)
