@@ -1,0 +1,12 @@
+"""ctc_amd -- MI355X-native CTC loss engine (hand-written HIP for gfx950).
+
+Drop-in for the loss path of gotaku6629/CTC: ``CTCLoss.apply`` plus ``NoBlankCTC`` /
+``NoBlankBinaryCTC`` / ``BlankCTC`` modules over the C ABI of include/ctc_amd.h.
+"""
+from ._lib import CtcAmdError, SO_PATH  # noqa: F401
+from .functional import (CTCLoss, binary_ctc_loss, blank_ctc_loss,  # noqa: F401
+                         noblank_ctc_loss)
+from .modules import BlankCTC, NoBlankBinaryCTC, NoBlankCTC  # noqa: F401
+
+__all__ = ["CTCLoss", "NoBlankCTC", "NoBlankBinaryCTC", "BlankCTC", "noblank_ctc_loss",
+           "binary_ctc_loss", "blank_ctc_loss", "CtcAmdError"]

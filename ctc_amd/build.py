@@ -1,0 +1,65 @@
+"""Build libctc_amd.so (the C-ABI library, include/ctc_amd.h) with hipcc for gfx950.
+
+    python -m ctc_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is built IN-TREE (ctc_amd/lib/), is
+git-ignored, and travels to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+SO = os.path.join(LIBDIR, "libctc_amd.so")
+SOURCES = ["api.hip", "noblank.hip", "binary.hip", "blank.hip", "decode.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build libctc_amd.so")
+    return exe
+
+
+def _stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+           [os.path.join(HERE, "..", "include", "ctc_amd.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return SO
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    objs = []
+    for src, obj, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
+        if verbose and out:
+            print(out.decode())
+        objs.append(obj)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO + ".tmp", *objs])
+    os.replace(SO + ".tmp", SO)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

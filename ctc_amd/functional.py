@@ -1,0 +1,218 @@
+"""autograd.Function front-end of the HIP CTC engine.
+
+Surface (BASELINE north_star): ``CTCLoss.apply(log_probs, targets, input_lengths,
+target_lengths)`` -> 0-dim fp32 loss, differentiable w.r.t. ``log_probs``.
+
+Mirrors the call convention of the reference's loss modules
+(``ctc_loss(v_output, v_target, input_length, v_target_length)``, train.py:427,576):
+
+* ``log_probs`` are RAW LOGITS [T,B,C] -- the module applies LogSoftmax(dim=2)
+  (NoBlankCTC.py:136) / Sigmoid (NoBlankBinaryCTC.py:146) itself; the returned
+  gradient is w.r.t. those logits.
+* ``targets`` [B,S] integer class indices (int32 or int64, -1 padded) selects the
+  no-blank loss; [B,S,C] float multi-hot rows selects the binary variant.
+* loss = mean over the batch only, no division by target length (NoBlankCTC.py:139-140).
+
+Forward runs ONE fused HIP launch that produces the loss and (when the input needs
+a gradient) the whole input gradient; backward multiplies that buffer by the upstream
+gradient on the device (a no-op launch when it is 1.0, i.e. ``loss.backward()``).
+There is no CPU path: non-HIP tensors raise.
+"""
+import os
+
+import torch
+
+from . import _lib
+
+_workspaces = {}
+_VALIDATE = os.environ.get("CTC_AMD_VALIDATE", "0") == "1"
+
+
+def _stream_handle(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _workspace(variant, T, B, C, S, device):
+    """Zero-initialised once, one per (device, stream): see include/ctc_amd.h."""
+    need = _lib.load().ctc_amd_workspace_bytes(variant, T, B, C, S)
+    key = (device.index, _stream_handle(device), variant)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _require_hip(x, name):
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise _lib.CtcAmdError(
+            "ctc_amd: %s must be a tensor on a HIP (cuda) device -- the engine has no CPU path" % name)
+
+
+def _lengths(v, B, lo_name, device, hi, lo=1):
+    """-> int64 device tensor [B]; values are validated on the host only when that
+    costs no device synchronisation (CPU input) or CTC_AMD_VALIDATE=1."""
+    if not isinstance(v, torch.Tensor):
+        v = torch.as_tensor(v, dtype=torch.int64)
+    if v.dim() != 1 or v.numel() != B:
+        raise ValueError("ctc_amd: %s must have shape [%d], got %s" % (lo_name, B, tuple(v.shape)))
+    if v.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8, torch.int8):
+        raise ValueError("ctc_amd: %s must be an integer tensor, got %s" % (lo_name, v.dtype))
+    if not v.is_cuda or _VALIDATE:
+        h = v.detach().cpu()
+        if h.numel() and (int(h.min()) < lo or int(h.max()) > hi):
+            raise ValueError("ctc_amd: %s must lie in [%d, %d]" % (lo_name, lo, hi))
+    return v.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
+
+
+def _variant_of(targets):
+    if targets.dim() == 2 and not targets.dtype.is_floating_point:
+        return _lib.NOBLANK
+    if targets.dim() == 3 and targets.dtype.is_floating_point:
+        return _lib.BINARY
+    raise ValueError("ctc_amd: targets must be [B,S] integer (no-blank) or [B,S,C] float (binary), got "
+                     "%s %s" % (tuple(targets.shape), targets.dtype))
+
+
+def _launch(variant, x, targets, in_len, tgt_len, want_grad, batch_total, blank=0):
+    """Validate, allocate outputs and enqueue the fused kernel.  -> (loss, nll, grad|None)"""
+    _require_hip(x, "log_probs")
+    if x.dim() != 3:
+        raise ValueError("ctc_amd: log_probs must be [T,B,C], got %s" % (tuple(x.shape),))
+    if x.dtype != torch.float32:
+        raise ValueError("ctc_amd: log_probs must be float32 (the engine computes in fp32), got %s" % x.dtype)
+    T, B, C = x.shape
+    if T < 1 or B < 1 or C < 1:
+        raise ValueError("ctc_amd: empty log_probs %s" % (tuple(x.shape),))
+    dev = x.device
+    xs = x.detach()
+    if xs.stride(2) != 1:
+        xs = xs.contiguous()
+    if not isinstance(targets, torch.Tensor):
+        raise ValueError("ctc_amd: targets must be a tensor")
+    if targets.shape[0] != B:
+        raise ValueError("ctc_amd: targets batch %d != log_probs batch %d" % (targets.shape[0], B))
+    S = targets.shape[1]
+    if S < 1:
+        raise ValueError("ctc_amd: targets need at least one label column")
+    if variant == _lib.BINARY:
+        if targets.shape[2] != C:
+            raise ValueError("ctc_amd: binary targets last dim %d != C %d" % (targets.shape[2], C))
+        tg = targets.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+    else:
+        if targets.dtype not in (torch.int32, torch.int64):
+            targets = targets.long()
+        tg = targets.to(device=dev, non_blocking=True).contiguous()
+    il = _lengths(in_len, B, "input_lengths", dev, T)
+    tl = _lengths(tgt_len, B, "target_lengths", dev, S, lo=0 if variant == _lib.BLANK else 1)
+    total = B if batch_total is None else int(batch_total)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    grad = torch.empty((T, B, C), dtype=torch.float32, device=dev) if want_grad else None
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        ws = _workspace(variant, T, B, C, S, dev)
+        stream = _stream_handle(dev)
+        gp = grad.data_ptr() if want_grad else None
+        scale = 1.0 / total
+        if variant == _lib.NOBLANK:
+            rc = lib.ctc_amd_noblank_loss_grad(
+                xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(), int(tg.dtype == torch.int64),
+                il.data_ptr(), tl.data_ptr(), T, B, C, S, scale, scale,
+                nll.data_ptr(), loss.data_ptr(), gp, ws.data_ptr(), stream)
+            _lib.check(rc, "ctc_amd_noblank_loss_grad")
+        elif variant == _lib.BINARY:
+            rc = lib.ctc_amd_binary_loss_grad(
+                xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(),
+                il.data_ptr(), tl.data_ptr(), T, B, C, S, scale, scale,
+                nll.data_ptr(), loss.data_ptr(), gp, ws.data_ptr(), stream)
+            _lib.check(rc, "ctc_amd_binary_loss_grad")
+        else:
+            rc = lib.ctc_amd_blank_loss_grad(
+                xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(), int(tg.dtype == torch.int64),
+                il.data_ptr(), tl.data_ptr(), T, B, C, S, int(blank), scale, scale,
+                nll.data_ptr(), loss.data_ptr(), gp, ws.data_ptr(), stream)
+            _lib.check(rc, "ctc_amd_blank_loss_grad")
+    return loss, nll, grad
+
+
+def _scaled_grad(ctx, gout):
+    """upstream gradient x the buffer the forward launch filled (in place, on device)."""
+    grad = ctx.grad
+    ctx.grad = None                         # the buffer is handed to autograd exactly once
+    if grad is None:                        # backward again (retain_graph): recompute
+        x, targets = ctx.saved_tensors
+        variant, batch_total, blank = ctx.meta
+        _, _, grad = _launch(variant, x, targets, ctx.lens[0], ctx.lens[1], True, batch_total, blank)
+    g = gout.detach().to(device=grad.device, dtype=torch.float32).contiguous()
+    with torch.cuda.device(grad.device):
+        rc = _lib.load().ctc_amd_scale_grad(grad.data_ptr(), g.data_ptr(), grad.numel(),
+                                            _stream_handle(grad.device))
+    _lib.check(rc, "ctc_amd_scale_grad")
+    return grad
+
+
+class _LossFn(torch.autograd.Function):
+    """(loss, nll) with the input gradient produced by the forward launch."""
+
+    @staticmethod
+    def forward(ctx, x, targets, in_len, tgt_len, variant, batch_total, blank):
+        want = ctx.needs_input_grad[0]
+        loss, nll, grad = _launch(variant, x, targets, in_len, tgt_len, want, batch_total, blank)
+        ctx.grad = grad
+        ctx.meta = (variant, batch_total, blank)
+        if want:
+            ctx.save_for_backward(x, targets)
+            ctx.lens = (in_len, tgt_len)
+        ctx.mark_non_differentiable(nll)
+        return loss, nll
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout, _gnll):
+        return _scaled_grad(ctx, gout), None, None, None, None, None, None
+
+
+class CTCLoss(torch.autograd.Function):
+    """Drop-in ``CTCLoss.apply(log_probs, targets, input_lengths, target_lengths)``.
+
+    The variant follows the targets: [B,S] integer -> NoBlankCTC arithmetic
+    (NoBlankCTC.py:129-141), [B,S,C] float -> NoBlankBinaryCTC (NoBlankBinaryCTC.py:139-151).
+    Optional 5th argument ``batch_total``: global batch size when this call sees only a
+    shard (loss and gradient are scaled by 1/batch_total; see ctc_amd.distributed).
+    """
+
+    @staticmethod
+    def forward(ctx, log_probs, targets, input_lengths, target_lengths, batch_total=None):
+        variant = _variant_of(targets)
+        want = ctx.needs_input_grad[0]
+        loss, nll, grad = _launch(variant, log_probs, targets, input_lengths, target_lengths, want,
+                                  batch_total)
+        ctx.grad = grad
+        ctx.meta = (variant, batch_total, 0)
+        if want:
+            ctx.save_for_backward(log_probs, targets)
+            ctx.lens = (input_lengths, target_lengths)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        return _scaled_grad(ctx, gout), None, None, None, None
+
+
+def noblank_ctc_loss(logits, targets, input_lengths, target_lengths, batch_total=None):
+    """-> (loss, nll[B]); NoBlankCTC arithmetic."""
+    return _LossFn.apply(logits, targets, input_lengths, target_lengths, _lib.NOBLANK, batch_total, 0)
+
+
+def binary_ctc_loss(logits, targets, input_lengths, target_lengths, batch_total=None):
+    """-> (loss, nll[B]); NoBlankBinaryCTC arithmetic."""
+    return _LossFn.apply(logits, targets, input_lengths, target_lengths, _lib.BINARY, batch_total, 0)
+
+
+def blank_ctc_loss(log_probs, targets, input_lengths, target_lengths, blank=0, batch_total=None):
+    """-> (loss, nll[B]); torch.nn.CTCLoss(blank, reduction='mean', zero_infinity=False)
+    semantics (models/layers/AsyncTFCriterion.py:198): log_probs are normalised
+    log-probabilities, loss = mean_b(nll_b / max(L_b,1))."""
+    return _LossFn.apply(log_probs, targets, input_lengths, target_lengths, _lib.BLANK, batch_total, blank)

@@ -1,0 +1,121 @@
+/* ctc_amd.h -- C ABI of the MI355X-native CTC loss engine (libctc_amd.so).
+ *
+ * The drop-in boundary for the reference's loss path.  The reference has no FFI:
+ * its loss is two Python nn.Modules (NoBlankCTC.py:22-141, NoBlankBinaryCTC.py:22-151)
+ * called as  loss = ctc_loss(v_output, v_target, input_length, v_target_length)
+ * (train.py:427, 576) followed by  loss.backward()  (train.py:444), plus
+ * torch.nn.CTCLoss(blank=0) at models/layers/AsyncTFCriterion.py:198,319-321.
+ * Each entry point below replaces one of those call sites' device work; the Python
+ * host layer (ctc_amd/) binds them with ctypes and mirrors the modules' signatures.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only
+ *    enqueue work: no allocation, no host synchronisation, graph-capture safe;
+ *  - inputs are read-only; outputs are fully overwritten (grad rows t >= T_b get 0);
+ *  - the caller owns all memory.  `workspace` must hold ctc_amd_workspace_bytes(...)
+ *    bytes, be zero-filled ONCE when allocated, and not be shared by launches that
+ *    may run concurrently (one workspace per stream);
+ *  - return value: 0 on success, a hipError_t (> 0) from the launch, or one of the
+ *    negative CTC_AMD_ERR_* codes; ctc_amd_error_string() describes any of them.
+ */
+#ifndef CTC_AMD_H
+#define CTC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTC_AMD_ABI_VERSION 1
+
+#define CTC_AMD_ERR_BAD_ARGUMENT      (-1)  /* null pointer, non-positive size ... */
+#define CTC_AMD_ERR_UNSUPPORTED_SHAPE (-2)  /* S or T*S beyond what the kernels tile */
+
+/* variants for ctc_amd_workspace_bytes */
+#define CTC_AMD_NOBLANK 0
+#define CTC_AMD_BINARY  1
+#define CTC_AMD_BLANK   2
+
+int ctc_amd_abi_version(void);
+const char *ctc_amd_error_string(int code);
+
+/* Bytes of device workspace a *_loss_grad call of this shape needs (>= 256). */
+size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int S);
+
+/* NoBlankCTC.forward (NoBlankCTC.py:129-141) + the gradient autograd would produce
+ * for it (train.py:444), one fused launch.
+ *   x        [T,B,C] fp32 raw logits, element strides stride_t / stride_b, unit
+ *            stride over C (the module applies LogSoftmax(dim=2) itself, :136)
+ *   labels   [B,S] class indices, int32 (labels_i64 = 0) or int64 (= 1); entries at
+ *            l >= tgt_len[b] are never dereferenced (the dataset pads with -1)
+ *   in_len   [B] int64, 1 <= T_b <= T        tgt_len [B] int64, 1 <= L_b <= S
+ *   nll      [B]  out: -alpha[T_b-1, L_b-1]  (1e13 when no alignment exists)
+ *   loss     [1]  out: loss_scale * sum_b nll[b]   (loss_scale = 1/B for the
+ *            reference's batch mean :139-140; 1/B_global on a batch shard)
+ *   grad     [T,B,C] contiguous out, or NULL for a forward-only call:
+ *            grad_scale * (softmax(x)[t,b,c] - sum_{l<L_b, lab[b,l]=c} gamma_t(l)),
+ *            exactly 0 for t >= T_b and for samples with no alignment
+ */
+int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64_t stride_b,
+                              const void *labels, int labels_i64,
+                              const int64_t *in_len, const int64_t *tgt_len,
+                              int T, int B, int C, int S,
+                              float loss_scale, float grad_scale,
+                              float *nll, float *loss, float *grad,
+                              void *workspace, void *stream);
+
+/* NoBlankBinaryCTC.forward (NoBlankBinaryCTC.py:139-151) + gradient.  Same as above
+ * except   y [B,S,C] fp32 multi-hot / soft targets in [0,1], contiguous;
+ * emission = -BCELoss(sigmoid(x[t,b,:]), y[b,l,:]) (:112,:88, logs clamped at -100);
+ * grad = grad_scale/C * (sigmoid(x) - sum_l gamma_t(l) y[b,l,c]).
+ */
+int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_t stride_b,
+                             const float *y,
+                             const int64_t *in_len, const int64_t *tgt_len,
+                             int T, int B, int C, int S,
+                             float loss_scale, float grad_scale,
+                             float *nll, float *loss, float *grad,
+                             void *workspace, void *stream);
+
+/* torch.nn.CTCLoss(blank, reduction='mean', zero_infinity=False) as used at
+ * models/layers/AsyncTFCriterion.py:198,319-321 (padded [B,S] targets).
+ *   log_probs [T,B,C] fp32, already normalised; targets [B,S] int32/int64
+ *   nll   [B]  out: un-normalised negative log-likelihood (+inf if infeasible)
+ *   loss  [1]  out: loss_scale * sum_b nll[b] / max(L_b,1)
+ *   grad  [T,B,C] out or NULL: (exp(lp) - occupancy) * grad_scale / max(L_b,1)
+ */
+int ctc_amd_blank_loss_grad(const float *log_probs, int64_t stride_t, int64_t stride_b,
+                            const void *targets, int targets_i64,
+                            const int64_t *in_len, const int64_t *tgt_len,
+                            int T, int B, int C, int S, int blank,
+                            float loss_scale, float grad_scale,
+                            float *nll, float *loss, float *grad,
+                            void *workspace, void *stream);
+
+/* backward of the autograd.Function: grad[i] *= *grad_out (a device scalar, the
+ * upstream gradient of the 0-dim loss).  Every workgroup reads *grad_out and exits
+ * at once when it is exactly 1.0f (the loss.backward() case, train.py:444), so the
+ * common case moves no data and needs no host synchronisation. */
+int ctc_amd_scale_grad(float *grad, const float *grad_out, size_t n, void *stream);
+
+/* Best-path (Viterbi) alignment on the no-blank lattice: the max-semiring twin of
+ * the alpha recursion (the reference evaluates with per-step argmax and
+ * DTW-like helpers, train.py:82-136,434).
+ *   path  [B,T] int32 out: label position l_t of the best alignment for t < T_b,
+ *         -1 for t >= T_b or when no alignment exists
+ *   score [B]   out: log-probability of that alignment
+ */
+int ctc_amd_noblank_best_path(const float *x, int64_t stride_t, int64_t stride_b,
+                              const void *labels, int labels_i64,
+                              const int64_t *in_len, const int64_t *tgt_len,
+                              int T, int B, int C, int S,
+                              int32_t *path, float *score,
+                              void *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTC_AMD_H */

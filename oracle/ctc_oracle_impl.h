@@ -83,7 +83,7 @@ void FN(oracle_noblank)(const REAL *x, const long *lab, const long *in_len, cons
             for (int t = 0; t < T; ++t) {
                 const REAL *r = x + ((long)t * B + b) * C;
                 REAL *g = grad + ((long)t * B + b) * C;
-                if (t >= in_len[b]) { for (int c = 0; c < C; ++c) g[c] = 0; continue; }
+                if (t >= in_len[b] || !(nll[b] < (REAL)1e12)) { for (int c = 0; c < C; ++c) g[c] = 0; continue; }
                 for (int c = 0; c < C; ++c) g[c] = (REAL)EXPF((r[c] - mx[t]) - lse[t]);
                 for (int l = 0; l < S && l < tgt_len[b]; ++l) {
                     long k = lab[(long)b * S + l];
@@ -130,7 +130,7 @@ void FN(oracle_binary)(const REAL *x, const REAL *y, const long *in_len, const l
             for (int t = 0; t < T; ++t) {
                 const REAL *r = x + ((long)t * B + b) * C;
                 REAL *g = grad + ((long)t * B + b) * C;
-                if (t >= in_len[b]) { for (int c = 0; c < C; ++c) g[c] = 0; continue; }
+                if (t >= in_len[b] || !(nll[b] < (REAL)1e12)) { for (int c = 0; c < C; ++c) g[c] = 0; continue; }
                 REAL tot = 0;
                 for (int l = 0; l < S; ++l) tot += gam[t * S + l];
                 for (int c = 0; c < C; ++c) {

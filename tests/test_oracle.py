@@ -1,0 +1,98 @@
+"""The oracle against the golden vectors captured from the reference (CPU only)."""
+import numpy as np
+import pytest
+
+from oracle import ctc_c, ctc_numpy
+
+NOBLANK = ["kat1_noblank", "kat3_noblank", "cfg1_noblank", "charades_noblank", "edge_noblank"]
+BINARY = ["kat2_binary", "cfg1_binary", "charades_binary", "edge_binary"]
+BLANK = ["blank_small", "blank_long"]
+
+
+def _check(r, d, nll_tol, grad_tol):
+    # float32 forward keeps the reference's operation order: nll agrees to an ulp or two
+    assert np.abs(r["nll"] - d["nll"]).max() <= nll_tol * max(1.0, np.abs(d["nll"]).max())
+    assert abs(float(r["loss"]) - float(d["loss"])) <= nll_tol * max(1.0, abs(float(d["loss"])))
+    assert np.abs(r["grad"] - d["grad"]).max() <= grad_tol
+
+
+@pytest.mark.parametrize("impl", [ctc_numpy, ctc_c], ids=["numpy", "c"])
+@pytest.mark.parametrize("name", NOBLANK)
+def test_noblank_vs_reference(golden, impl, name):
+    d = golden(name)
+    _check(impl.noblank_ctc(d["x"], d["lab"], d["in_len"], d["tgt_len"], np.float32), d, 3e-7, 5e-5)
+    _check(impl.noblank_ctc(d["x"], d["lab"], d["in_len"], d["tgt_len"], np.float64), d, 1e-6, 1e-5)
+
+
+@pytest.mark.parametrize("impl", [ctc_numpy, ctc_c], ids=["numpy", "c"])
+@pytest.mark.parametrize("name", BINARY)
+def test_binary_vs_reference(golden, impl, name):
+    d = golden(name)
+    _check(impl.binary_ctc(d["x"], d["y"], d["in_len"], d["tgt_len"], np.float32), d, 1e-6, 1e-6)
+    _check(impl.binary_ctc(d["x"], d["y"], d["in_len"], d["tgt_len"], np.float64), d, 2e-6, 1e-6)
+
+
+@pytest.mark.parametrize("impl", [ctc_numpy, ctc_c], ids=["numpy", "c"])
+@pytest.mark.parametrize("name", BLANK)
+def test_blank_vs_torch(golden, impl, name):
+    d = golden(name)
+    _check(impl.blank_ctc(d["lp"], d["tgt"], d["in_len"], d["tgt_len"], np.float32), d, 1e-6, 1e-5)
+    _check(impl.blank_ctc(d["lp"], d["tgt"], d["in_len"], d["tgt_len"], np.float64), d, 5e-6, 1e-5)
+
+
+def test_known_answers(golden):
+    # SURVEY section 4 KAT table (values produced by the shipped reference modules)
+    d = golden("kat1_noblank")
+    assert abs(float(d["loss"]) - 6.62364197) < 1e-6
+    assert np.allclose(d["nll"], [7.22587299, 6.02141142], atol=1e-6)
+    assert np.allclose(d["grad"][0, 0], [0.06152686, 0.18483686, -0.42485094, 0.01123994, 0.16724733], atol=1e-7)
+    assert abs(float(golden("kat2_binary")["loss"]) - 4.01820946) < 1e-6
+    assert abs(float(golden("kat3_noblank")["loss"]) - 7.22587299) < 1e-6
+
+
+def test_blank_matches_torch_live():
+    torch = pytest.importorskip("torch")
+    from tests.helpers import synth_blank
+    lp, tgt, Tb, L = synth_blank(11, 60, 5, 17, 9, var_T=True)
+    lp = lp.requires_grad_(True)
+    loss = torch.nn.functional.ctc_loss(lp, tgt, Tb, L, blank=0, reduction="mean")
+    loss.backward()
+    r = ctc_c.blank_ctc(lp.detach().numpy(), tgt.numpy(), Tb.numpy(), L.numpy())
+    assert abs(float(r["loss"]) - float(loss)) < 1e-5
+    assert np.abs(r["grad"] - lp.grad.numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("which", ["noblank", "binary"])
+def test_gradient_is_derivative_of_loss(which):
+    """closed-form alpha-beta gradient == finite differences of the float64 loss."""
+    rng = np.random.default_rng(3)
+    T, B, C, S = 7, 3, 5, 4
+    x = rng.standard_normal((T, B, C))
+    L = np.array([4, 2, 1]); Tb = np.array([7, 5, 7])
+    if which == "noblank":
+        tg = rng.integers(0, C, (B, S)); tg[0, 1] = tg[0, 0]
+        f = lambda z: ctc_numpy.noblank_ctc(z, tg, Tb, L, np.float64)
+    else:
+        tg = rng.random((B, S, C))
+        f = lambda z: ctc_numpy.binary_ctc(z, tg, Tb, L, np.float64)
+    g = f(x)["grad"]
+    num = np.zeros_like(x)
+    for i in np.ndindex(*x.shape):
+        xp = x.copy(); xp[i] += 1e-6
+        xm = x.copy(); xm[i] -= 1e-6
+        num[i] = (f(xp)["loss"] - f(xm)["loss"]) / 2e-6
+    assert np.abs(num - g).max() < 1e-7
+    assert np.abs(g[6, 1]).max() == 0.0          # rows t >= T_b carry no gradient
+
+
+def test_numpy_and_c_agree_on_random_shapes():
+    from tests.helpers import synth_noblank, synth_binary, np_
+    for seed, (T, B, C, S) in enumerate([(20, 4, 10, 5), (33, 6, 70, 64), (10, 10, 33, 10)]):
+        x, lab, Tb, L = map(np_, synth_noblank(seed, T, B, C, S, var_T=True))
+        a = ctc_numpy.noblank_ctc(x, lab, Tb, L, np.float64)
+        c = ctc_c.noblank_ctc(x, lab, Tb, L, np.float64, threads=2)
+        assert np.abs(a["nll"] - c["nll"]).max() < 1e-9 and np.abs(a["grad"] - c["grad"]).max() < 1e-12
+        x, y, Tb, L = map(np_, synth_binary(seed, T, B, C, S, var_T=True, density=0.2))
+        a = ctc_numpy.binary_ctc(x, y, Tb, L, np.float64)
+        c = ctc_c.binary_ctc(x, y, Tb, L, np.float64, threads=2)
+        assert np.abs(a["nll"] - c["nll"]).max() < 1e-9 and np.abs(a["grad"] - c["grad"]).max() < 1e-12

@@ -1,0 +1,141 @@
+"""HIP path vs the oracle / golden vectors, through the C ABI.  Needs an MI355X.
+
+Tolerances (BASELINE north_star: loss and input-gradient within 1e-4 of the reference,
+fp32): per-sample nll and the mean loss relative 1e-5 (abs 1e-4 on values of a few
+hundred), gradients abs 1e-4 against the reference's own autograd gradient and abs
+2e-6*max(1, 256/B) against the float64 oracle at full size.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc_c, ctc_numpy
+from tests.helpers import np_, synth_binary, synth_blank, synth_noblank
+
+pytestmark = pytest.mark.gpu
+
+NLL_RTOL = 1e-5
+GRAD_ATOL_REF = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    import ctc_amd  # noqa: F401  (raises if libctc_amd.so is missing)
+    return torch.device("cuda:0")
+
+
+def run_hip(fn, x, tg, il, tl, dev, lens_on_gpu=True, **kw):
+    xd = torch.as_tensor(x, dtype=torch.float32).to(dev).requires_grad_(True)
+    tgd = torch.as_tensor(tg).to(dev)
+    ild, tld = torch.as_tensor(il), torch.as_tensor(tl)
+    if lens_on_gpu:
+        ild, tld = ild.to(dev), tld.to(dev)
+    loss, nll = fn(xd, tgd, ild, tld, **kw)
+    loss.backward()
+    torch.cuda.synchronize()
+    return {"loss": float(loss), "nll": np_(nll), "grad": np_(xd.grad)}
+
+
+def assert_close(r, ref, grad_atol, nll_rtol=NLL_RTOL):
+    scale = np.maximum(1.0, np.abs(ref["nll"]))
+    assert (np.abs(r["nll"] - ref["nll"]) <= nll_rtol * scale).all(), np.abs(r["nll"] - ref["nll"]).max()
+    assert abs(r["loss"] - float(ref["loss"])) <= nll_rtol * max(1.0, abs(float(ref["loss"])))
+    assert np.isfinite(r["grad"]).all()
+    err = np.abs(r["grad"] - ref["grad"]).max()
+    assert err <= grad_atol, err
+
+
+# ------------------------------------------------------------------ no-blank
+@pytest.mark.parametrize("name", ["kat1_noblank", "kat3_noblank", "cfg1_noblank", "charades_noblank",
+                                  "edge_noblank"])
+def test_noblank_golden(golden, dev, name):
+    import ctc_amd
+    d = golden(name)
+    r = run_hip(ctc_amd.noblank_ctc_loss, d["x"], d["lab"], d["in_len"], d["tgt_len"], dev)
+    assert_close(r, d, GRAD_ATOL_REF)
+    # rows beyond T_b carry exactly zero gradient
+    for b, tb in enumerate(d["in_len"]):
+        assert np.abs(r["grad"][int(tb):, b]).max(initial=0.0) == 0.0
+
+
+def test_noblank_modules_and_function_surface(golden, dev):
+    import ctc_amd
+    d = golden("cfg1_noblank")
+    x = torch.tensor(d["x"]).to(dev).requires_grad_(True)
+    lab = torch.tensor(d["lab"]).to(dev)          # int32, -1 padded, as the dataset emits
+    il, tl = torch.tensor(d["in_len"]).to(dev), torch.tensor(d["tgt_len"]).to(dev)
+    loss = ctc_amd.CTCLoss.apply(x, lab, il, tl)
+    assert loss.dim() == 0 and loss.dtype == torch.float32
+    loss.backward()
+    assert abs(float(loss) - float(d["loss"])) < 1e-4
+    assert np.abs(np_(x.grad) - d["grad"]).max() < GRAD_ATOL_REF
+    m = ctc_amd.NoBlankCTC().to(dev)
+    x2 = torch.tensor(d["x"]).to(dev).requires_grad_(True)
+    loss2 = m(x2, lab.long(), il.cpu(), tl.cpu())  # int64 labels, CPU lengths
+    (3.0 * loss2).backward()                       # upstream gradient != 1
+    assert abs(float(loss2) - float(d["loss"])) < 1e-4
+    assert np.abs(np_(x2.grad) - 3.0 * d["grad"]).max() < 3 * GRAD_ATOL_REF
+    with torch.no_grad():
+        assert abs(float(m(x2, lab, il, tl)) - float(d["loss"])) < 1e-4
+
+
+def test_noblank_noncontiguous_and_retain_graph(dev):
+    import ctc_amd
+    x, lab, Tb, L = synth_noblank(5, 12, 6, 9, 4, var_T=True)
+    ref = ctc_numpy.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    xb = x.permute(1, 0, 2).contiguous().to(dev)          # [B,T,C] storage
+    xv = xb.permute(1, 0, 2).requires_grad_(True)         # [T,B,C] view, strides (C, T*C, 1)
+    loss, _ = ctc_amd.noblank_ctc_loss(xv, lab.to(dev), Tb.to(dev), L.to(dev))
+    loss.backward(retain_graph=True)
+    g1 = np_(xv.grad).copy()
+    xv.grad = None
+    loss.backward()
+    assert np.abs(g1 - ref["grad"]).max() < 2e-6 and np.abs(np_(xv.grad) - ref["grad"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(20, 4, 10, 5), (10, 10, 33, 10), (37, 5, 64, 7), (16, 3, 65, 16),
+                                   (50, 6, 200, 50), (40, 3, 300, 12), (130, 2, 40, 100), (150, 8, 158, 20)])
+@pytest.mark.parametrize("var_T", [False, True])
+def test_noblank_vs_oracle_shapes(dev, shape, var_T):
+    import ctc_amd
+    T, B, C, S = shape
+    x, lab, Tb, L = synth_noblank(sum(shape), T, B, C, S, var_T=var_T, int64=bool(T % 2))
+    ref = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+    assert_close(r, ref, 2e-6 * max(1.0, 256.0 / B))
+
+
+def test_noblank_config2_full_size(dev):
+    """B=256 T=150 C=158 S<=20: float32 oracle (reference op order) and float64 truth."""
+    import ctc_amd
+    x, lab, Tb, L = synth_noblank(0, 150, 256, 158, 20)
+    r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+    ref32 = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float32, threads=8)
+    ref64 = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64, threads=8)
+    assert_close(r, ref32, 2e-6)
+    assert_close(r, ref64, 2e-6)
+    # properties that hold at any size: every live row of the gradient sums to zero
+    # (softmax minus a distribution), dead rows are zero, mean of nll is the loss
+    assert np.abs(r["grad"].sum(axis=2)).max() < 1e-7
+    assert abs(r["nll"].mean() - r["loss"]) < 1e-3
+    # sharding property (config 4): a shard scaled by 1/B_global reproduces its slice
+    xs = x[:, 64:128].contiguous()
+    rs = run_hip(ctc_amd.noblank_ctc_loss, xs, lab[64:128], Tb[64:128], L[64:128], dev, batch_total=256)
+    assert np.abs(rs["grad"] - r["grad"][:, 64:128]).max() < 1e-9
+    assert np.abs(rs["nll"] - r["nll"][64:128]).max() == 0.0
+
+
+def test_noblank_infeasible_and_deterministic(dev):
+    import ctc_amd
+    x, lab, Tb, L = synth_noblank(9, 10, 4, 6, 8)
+    L[:] = torch.tensor([8, 2, 8, 1]); Tb[:] = torch.tensor([10, 10, 5, 10])   # sample 2: L > T_b
+    lab = torch.randint(0, 6, (4, 8), dtype=torch.int32)
+    r1 = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+    r2 = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+    assert r1["nll"][2] >= 1e12 and np.abs(r1["grad"][:, 2]).max() == 0.0
+    assert (r1["grad"] == r2["grad"]).all() and (r1["nll"] == r2["nll"]).all() and r1["loss"] == r2["loss"]
+    ref = ctc_numpy.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    ok = [0, 1, 3]
+    assert np.abs(r1["nll"][ok] - ref["nll"][ok]).max() < 1e-4
+    assert np.abs(r1["grad"][:, ok] - ref["grad"][:, ok]).max() < 1e-6
