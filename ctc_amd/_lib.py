@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libctc_amd.so")
+SO_PATH = os.environ.get("CTC_AMD_LIB") or os.path.join(_HERE, "lib", "libctc_amd.so")   # override: kernel experiments
 
 NOBLANK, BINARY, BLANK = 0, 1, 2
 

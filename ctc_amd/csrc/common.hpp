@@ -12,7 +12,8 @@ constexpr float kNeg = -10000000000000.0f;
 constexpr float kInfeasible = 1.0e12f;   // nll above this <=> no alignment exists
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// wave-uniform by construction: keep it in an SGPR so row indices / LDS row addresses are scalar
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
 // lane i <- lane i-1 (lane 0 keeps `fill`): DPP wave_shr:1, one VALU op, no LDS.
 __device__ __forceinline__ float wave_shr1(float v, float fill)
@@ -27,31 +28,82 @@ __device__ __forceinline__ float wave_shl1(float v, float fill)
         __builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+// DPP building block: lanes selected by `ctrl`/`row_mask` read `v` of their source lane,
+// all other lanes get `ident` (so a following op leaves them unchanged).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp(float v, float ident)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        __builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140;
+constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+
+// all-reduce inside each 16-lane DPP row: 4 VALU ops, no LDS round trip
+__device__ __forceinline__ float row16_max(float v)
+{
+    const float ni = -__builtin_inff();
+    v = fmaxf(v, dpp<kQuadXor1, 0xf>(v, ni));
+    v = fmaxf(v, dpp<kQuadXor2, 0xf>(v, ni));
+    v = fmaxf(v, dpp<kRowHalfMirror, 0xf>(v, ni));
+    v = fmaxf(v, dpp<kRowMirror, 0xf>(v, ni));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += dpp<kQuadXor1, 0xf>(v, 0.f);
+    v += dpp<kQuadXor2, 0xf>(v, 0.f);
+    v += dpp<kRowHalfMirror, 0xf>(v, 0.f);
+    v += dpp<kRowMirror, 0xf>(v, 0.f);
+    return v;
+}
+// whole-wave reductions: rows combined with row_bcast, result read from lane 63 into an
+// SGPR (wave-uniform).  6 DPP ops + 1 readlane.
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
-    return v;
+    const float ni = -__builtin_inff();
+    v = row16_max(v);
+    v = fmaxf(v, dpp<kRowBcast15, 0xa>(v, ni));
+    v = fmaxf(v, dpp<kRowBcast31, 0xc>(v, ni));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    v = row16_sum(v);
+    v += dpp<kRowBcast15, 0xa>(v, 0.f);
+    v += dpp<kRowBcast31, 0xc>(v, 0.f);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// all-reduce inside aligned groups of G = 16 / 32 / 64 lanes, every lane gets the result
+template <bool MAX>
+__device__ __forceinline__ float group_reduce(float v, int G)
+{
+    v = MAX ? row16_max(v) : row16_sum(v);
+    if (G >= 32) { const float o = __shfl_xor(v, 16, kWave); v = MAX ? fmaxf(v, o) : v + o; }
+    if (G >= 64) { const float o = __shfl_xor(v, 32, kWave); v = MAX ? fmaxf(v, o) : v + o; }
     return v;
 }
 
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+// natural log for arguments in the normal range (raw v_log_f32, no denormal fix-up)
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }
+
 // _logsumexp over two values (NoBlankCTC.py:16-19): max + log(exp(a-max)+exp(b-max))
-// == max + log(1 + exp(min-max)); v_exp_f32 / v_log_f32 based.
+// == max + log(1 + exp(-|a-b|)); the log argument lies in [1,2], so the raw
+// v_exp_f32 / v_log_f32 pair is exact enough (1 ulp) and needs no range fix-up.
 __device__ __forceinline__ float lse2(float a, float b)
 {
-    float m = fmaxf(a, b);
-    float d = fminf(a, b) - m;
-    return m + __logf(1.0f + __expf(d));
+    const float m = a > b ? a : b;
+    const float t = __builtin_amdgcn_exp2f(-fabsf(a - b) * kLog2e);
+    return __builtin_fmaf(__builtin_amdgcn_logf(1.0f + t), kLn2, m);
 }
 
-__device__ __forceinline__ int64_t load_label(const void *p, int is64, int64_t i)
+// labels arrive as int32 or int64 (little-endian): one branch-free 32-bit load of the
+// low word serves both (class indices and the -1 padding fit in 32 bits).
+__device__ __forceinline__ int load_label(const void *p, int is64, int64_t i)
 {
-    return is64 ? static_cast<const int64_t *>(p)[i] : (int64_t) static_cast<const int32_t *>(p)[i];
+    return static_cast<const int32_t *>(p)[is64 ? 2 * i : i];
 }
 
 // Deterministic batch reduction by the LAST workgroup to finish its nll (in-launch

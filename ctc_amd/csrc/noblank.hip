@@ -1,21 +1,27 @@
 // Fused no-blank CTC loss + input gradient for gfx950 (MI355X).
 //
 // Replaces NoBlankCTC.forward (NoBlankCTC.py:129-141) and the autograd backward the
-// reference runs over it (train.py:444).  One workgroup per sample b, one launch:
+// reference runs over it (train.py:444).  One 16-wave workgroup per sample b, one launch:
 //
-//   P1  every wave streams rows x[t,b,:] (R rows in flight per wave), reduces the
-//       row max / sum-exp (LogSoftmax(dim=2), :136) and gathers the S emissions
-//       e[t,l] = lp[t, lab[l]] (:96-102) into LDS;
+//   P1  at kernel entry every wave issues the loads of its kRows rows x[t,b,:]
+//       (coalesced 256-B requests; the rows then STAY in registers until P3).  While
+//       they are in flight the workgroup builds the label tables.  Row max / sum-exp
+//       (LogSoftmax(dim=2), :136) by DPP reductions; the S emissions
+//       e[t,l] = lp[t, lab[l]] (:96-102) are gathered out of the row registers with
+//       ds_bpermute and stored to LDS.
 //   P2  wave 0 runs the alpha scan, wave 1 the mirrored beta' scan, concurrently,
-//       one lattice row per step, states across lanes (lattice.hpp);
-//   P3  gamma = exp(alpha + beta' - e + nll) in LDS, then every wave re-reads its
-//       rows of x (L2-resident: the workgroup fetched them in P1) and writes
-//       grad = scale * (softmax(x) - sum_{l: lab[l]=c} gamma_t(l)) with 256-B
-//       coalesced stores.  Repeated labels are resolved with a first-occurrence map
-//       + next-duplicate chain, so the row write is conflict-free and deterministic.
+//       one lattice row per step, states across lanes (lattice.hpp).
+//   P3  each wave turns its own rows into gradient: gamma_t = softmax_l(alpha_t +
+//       beta'_t - e_t) (row-normalised; repeated labels folded onto the first
+//       occurrence), grad = scale * (softmax(x) - gamma scattered by class) from the
+//       resident row registers, written with 256-B coalesced stores.
 //
 // The batch mean is taken in-launch by the last workgroup to publish its nll
 // (common.hpp), overlapped with P3.  HBM traffic = read x once, write grad once.
+// Shapes beyond the register-resident tiling (T > 160 rows per pass, C > 256) fall
+// back to re-reading rows from L2 in P3 / to strided row passes.
+#include <cstdlib>
+
 #include "lattice.hpp"
 #include "launch.hpp"
 
@@ -28,127 +34,110 @@ struct NoblankParams {
     int lab64;
     const int64_t *in_len, *tgt_len;
     int T, B, C, S, SP;
+    int stop;                   // debug: leave after phase `stop` (0 = run everything);
+                                // < 0: workgroup 0 / wave -stop-1 stamps (s_memtime, s_memrealtime)
+                                // pairs into workspace bytes [64,256) at each phase boundary
     float loss_scale, grad_scale;
     float *nll, *loss, *grad;
     unsigned *counter;
 };
 
-constexpr int kThreads = 512;
-constexpr int kRows = 8;        // rows of x in flight per wave
+#ifndef CTC_NOBLANK_THREADS
+#define CTC_NOBLANK_THREADS 1024
+#endif
+constexpr int kThreads = CTC_NOBLANK_THREADS;  // 16 waves: one pass of kRows rows each covers T <= 160
+constexpr int kWaves = kThreads / kWave;
+constexpr int kRows = 160 / kWaves;            // rows of x resident per wave
+constexpr int kRowsPerPass = kWaves * kRows;
 
 struct NoblankSmem {
-    float *em, *al, *be, *mx, *ls;
-    int *lab, *nxt, *inv;
+    float *em, *al, *be, *mx, *ls, *dummy;
+    int *lab, *nxt, *dup, *inv;
     __device__ NoblankSmem(float *base, int T, int SP, int C)
     {
-        em = base;
-        al = em + (size_t)T * SP;
+        em = base + kPrefetch * SP;                     // pad rows on both sides (lattice.hpp)
+        al = em + (size_t)(T + kPrefetch) * SP;
         be = al + (size_t)T * SP;
         mx = be + (size_t)T * SP;
         ls = mx + T;
-        lab = reinterpret_cast<int *>(ls + T);
+        dummy = ls + T;
+        lab = reinterpret_cast<int *>(dummy + 8);
         nxt = lab + SP;
-        inv = nxt + SP;
+        dup = nxt + SP;
+        inv = dup + SP;
     }
 };
 
 static size_t noblank_smem_bytes(int T, int SP, int C)
 {
-    return ((size_t)3 * T * SP + 2 * (size_t)T + 2 * (size_t)SP + C + 4) * 4;
+    return ((size_t)(3 * T + 2 * kPrefetch) * SP + 2 * (size_t)T + 8 + 3 * (size_t)SP + C + 4) * 4;
 }
 
-// P1: rows -> (max, log-sum-exp) + emission gather.  CH = ceil(C/64) chunks per lane.
-template <int CH>
-__device__ __forceinline__ void rows_emit(const NoblankParams &p, const NoblankSmem &sm, int b, int Tb, int L)
+__device__ __forceinline__ const float *row_ptr(const NoblankParams &p, int t, int b)
 {
-    const int lane = lane_id(), nw = blockDim.x >> 6;
-    const float ninf = -__builtin_inff();
-    for (int t0 = wave_id() * kRows; t0 < Tb; t0 += nw * kRows) {
-        float v[kRows][CH];
-        float ev[kRows];
+    return p.x + (int64_t)t * p.st + (int64_t)b * p.sb;
+}
+
+// ---- register-resident rows (C <= 64*CH) ------------------------------------------
+template <int CH>
+struct Rows {
+    float v[kRows][CH];
+
+    // rows t0..t0+kRows-1.  Every load is issued unconditionally (row / column indices
+    // clamped into range) so that the compiler can wait for OLDER loads with an exact
+    // vmcnt(N) while these stay in flight; out-of-range values are masked at the use.
+    __device__ __forceinline__ void load(const NoblankParams &p, int b, int t0, int tmax)
+    {
+        const int lane = lane_id();
+        const int tlast = tmax > 0 ? tmax - 1 : 0;
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
-            const int t = t0 + r;
-            const float *row = p.x + (int64_t)t * p.st + (int64_t)b * p.sb;
+            const float *row = row_ptr(p, t0 + r < tlast ? t0 + r : tlast, b);
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const int c = lane + 64 * j;
-                v[r][j] = (t < Tb && c < p.C) ? row[c] : ninf;
+                v[r][j] = row[c < p.C ? c : p.C - 1];
             }
-            ev[r] = (t < Tb && lane < L) ? row[sm.lab[lane]] : 0.f;
         }
+    }
+
+    // LogSoftmax statistics + emission gather for rows < Tb (NoBlankCTC.py:136, :96-102)
+    __device__ __forceinline__ void emit(const NoblankParams &p, const NoblankSmem &sm, int t0, int Tb, int L)
+    {
+        const int lane = lane_id();
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
             const int t = t0 + r;
             if (t >= Tb) break;                              // wave-uniform
-            float m = v[r][0];
+            const float ninf = -__builtin_inff();
+            float m = ninf;
 #pragma unroll
-            for (int j = 1; j < CH; ++j) m = fmaxf(m, v[r][j]);
+            for (int j = 0; j < CH; ++j) m = fmaxf(m, lane + 64 * j < p.C ? v[r][j] : ninf);
             m = wave_max(m);
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < CH; ++j) s += __expf(v[r][j] - m);
+            for (int j = 0; j < CH; ++j) s += lane + 64 * j < p.C ? fast_exp(v[r][j] - m) : 0.f;
             s = wave_sum(s);
-            const float lsum = __logf(s);
+            const float lsum = fast_log(s);
             if (lane == 0) { sm.mx[t] = m; sm.ls[t] = lsum; }
-            if (lane < L) sm.em[t * p.SP + lane] = (ev[r] - m) - lsum;
-            if (L > kWave) {                                 // S > 64: remaining labels
-                const float *row = p.x + (int64_t)t * p.st + (int64_t)b * p.sb;
-                for (int l = lane + kWave; l < L; l += kWave)
-                    sm.em[t * p.SP + l] = (row[sm.lab[l]] - m) - lsum;
+            for (int lb = 0; lb < p.SP; lb += kWave) {       // wave-uniform trips (one when S <= 64):
+                const int l = lb + lane;                      // every lane must stay active, it is a
+                const int k = l < p.SP ? sm.lab[l] : 0;       // bpermute SOURCE for the other lanes
+                float xv = 0.f;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float q = __shfl(v[r][j], k & 63, kWave);
+                    if ((k >> 6) == j) xv = q;
+                }
+                if (l < p.SP) sm.em[t * p.SP + l] = (l < L) ? (xv - m) - lsum : kNeg;
             }
         }
     }
-}
 
-// P1 for C > 256: one row at a time, strided passes (rows come back from L1).
-__device__ __forceinline__ void rows_emit_generic(const NoblankParams &p, const NoblankSmem &sm, int b, int Tb, int L)
-{
-    const int lane = lane_id(), nw = blockDim.x >> 6;
-    for (int t = wave_id(); t < Tb; t += nw) {
-        const float *row = p.x + (int64_t)t * p.st + (int64_t)b * p.sb;
-        float m = -__builtin_inff();
-        for (int c = lane; c < p.C; c += kWave) m = fmaxf(m, row[c]);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int c = lane; c < p.C; c += kWave) s += __expf(row[c] - m);
-        s = wave_sum(s);
-        const float lsum = __logf(s);
-        if (lane == 0) { sm.mx[t] = m; sm.ls[t] = lsum; }
-        for (int l = lane; l < L; l += kWave) sm.em[t * p.SP + l] = (row[sm.lab[l]] - m) - lsum;
-    }
-}
-
-__device__ __forceinline__ float occupancy(const NoblankSmem &sm, int row_off, int first)
-{
-    float s = 0.f;
-    for (int n = first; n >= 0; n = sm.nxt[n]) s += sm.be[row_off + n];   // be holds gamma here
-    return s;
-}
-
-// P3: grad rows.  Tlive = rows with a gradient (0 when the sample has no alignment).
-template <int CH>
-__device__ __forceinline__ void rows_grad(const NoblankParams &p, const NoblankSmem &sm, int b, int Tlive)
-{
-    const int lane = lane_id(), nw = blockDim.x >> 6;
-    int first[CH];
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-        const int c = lane + 64 * j;
-        first[j] = (c < p.C) ? sm.inv[c] : -1;
-    }
-    for (int t0 = wave_id() * kRows; t0 < p.T; t0 += nw * kRows) {
-        float v[kRows][CH];
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            const int t = t0 + r;
-            const float *row = p.x + (int64_t)t * p.st + (int64_t)b * p.sb;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int c = lane + 64 * j;
-                v[r][j] = (t < Tlive && c < p.C) ? row[c] : 0.f;
-            }
-        }
+    __device__ __forceinline__ void grad(const NoblankParams &p, const NoblankSmem &sm, int b, int t0,
+                                         int Tlive, const int (&first)[CH])
+    {
+        const int lane = lane_id();
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
             const int t = t0 + r;
@@ -160,8 +149,8 @@ __device__ __forceinline__ void rows_grad(const NoblankParams &p, const NoblankS
                 for (int j = 0; j < CH; ++j) {
                     const int c = lane + 64 * j;
                     if (c < p.C) {
-                        const float pr = __expf((v[r][j] - m) - lsum);
-                        g[c] = p.grad_scale * (pr - occupancy(sm, t * p.SP, first[j]));
+                        const float occ = first[j] >= 0 ? sm.be[t * p.SP + first[j]] : 0.f;
+                        g[c] = p.grad_scale * (fast_exp((v[r][j] - m) - lsum) - occ);
                     }
                 }
             } else {
@@ -173,80 +162,157 @@ __device__ __forceinline__ void rows_grad(const NoblankParams &p, const NoblankS
             }
         }
     }
+};
+
+// ---- generic rows (C > 256): strided passes, rows come back from L1/L2 -------------
+__device__ __forceinline__ void rows_emit_generic(const NoblankParams &p, const NoblankSmem &sm, int b, int Tb, int L)
+{
+    const int lane = lane_id();
+    for (int t = wave_id(); t < Tb; t += kWaves) {
+        const float *row = row_ptr(p, t, b);
+        float m = -__builtin_inff();
+        for (int c = lane; c < p.C; c += kWave) m = fmaxf(m, row[c]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < p.C; c += kWave) s += fast_exp(row[c] - m);
+        s = wave_sum(s);
+        const float lsum = fast_log(s);
+        if (lane == 0) { sm.mx[t] = m; sm.ls[t] = lsum; }
+        for (int l = lane; l < p.SP; l += kWave)
+            sm.em[t * p.SP + l] = (l < L) ? (row[sm.lab[l]] - m) - lsum : kNeg;
+    }
 }
 
-__device__ __forceinline__ void rows_grad_generic(const NoblankParams &p, const NoblankSmem &sm, int b, int Tlive)
+__device__ __forceinline__ void rows_grad_generic(const NoblankParams &p, const NoblankSmem &sm, int b, int Tlive, int L)
 {
-    const int lane = lane_id(), nw = blockDim.x >> 6;
-    for (int t = wave_id(); t < p.T; t += nw) {
-        const float *row = p.x + (int64_t)t * p.st + (int64_t)b * p.sb;
+    const int lane = lane_id();
+    const int G = posterior_group(p.SP), per = kWave / G, sub = lane / G;
+    for (int t0 = wave_id() * per; t0 < Tlive; t0 += kWaves * per)
+        posterior_row(sm.al, sm.be, sm.em, sm.nxt, sm.dup, t0 + sub, t0 + sub < Tlive, L, p.SP, G);
+    __syncthreads();
+    for (int t = wave_id(); t < p.T; t += kWaves) {
+        const float *row = row_ptr(p, t, b);
         float *g = p.grad + ((int64_t)t * p.B + b) * p.C;
         if (t < Tlive) {
             const float m = sm.mx[t], lsum = sm.ls[t];
-            for (int c = lane; c < p.C; c += kWave)
-                g[c] = p.grad_scale * (__expf((row[c] - m) - lsum) - occupancy(sm, t * p.SP, sm.inv[c]));
+            for (int c = lane; c < p.C; c += kWave) {
+                const int f = sm.inv[c];
+                g[c] = p.grad_scale * (fast_exp((row[c] - m) - lsum) - (f >= 0 ? sm.be[t * p.SP + f] : 0.f));
+            }
         } else {
             for (int c = lane; c < p.C; c += kWave) g[c] = 0.f;
         }
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p)
+// label tables: lab[] (0 beyond L: those lanes only feed masked cells), first-occurrence
+// map inv[], next-duplicate chain nxt[], dup[] flags.  inv/nxt/dup are consumed in P3,
+// behind later barriers.
+__device__ __forceinline__ void build_label_tables(const NoblankParams &p, const NoblankSmem &sm, int raw_label, int L)
 {
-    extern __shared__ float4 smem_raw[];
-    const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C);
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
-    // contract: 1 <= L_b <= S, L_b <= T_b <= T (the dataset guarantees it,
-    // charades_ctc_next_pred.py:609-610); anything else has no alignment.
-    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
-    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
-    const int ch = (p.C + kWave - 1) / kWave;
-
-    // P0: labels, first-occurrence map, next-duplicate chain
-    for (int l = tid; l < p.SP; l += kThreads) {
-        int64_t k = -1;
-        if (l < L) {
-            k = load_label(p.lab, p.lab64, (int64_t)b * p.S + l) % p.C;
+    const int tid = threadIdx.x;
+    if (tid < p.SP) {                                        // SP <= 256 < kThreads
+        int k = 0;
+        if (tid < L) {
+            k = raw_label % p.C;
             if (k < 0) k += p.C;                             // python negative index (:102)
         }
-        sm.lab[l] = (int)k;
+        sm.lab[tid] = k;
     }
     for (int c = tid; c < p.C; c += kThreads) sm.inv[c] = 0x7fffffff;
     __syncthreads();
-    for (int l = tid; l < L; l += kThreads) {
-        const int k = sm.lab[l];
-        atomicMin(&sm.inv[k], l);
+    if (tid < L) {
+        const int k = sm.lab[tid];
+        atomicMin(&sm.inv[k], tid);
         int n = -1;
-        for (int l2 = l + 1; l2 < L; ++l2)
+        for (int l2 = tid + 1; l2 < L; ++l2)
             if (sm.lab[l2] == k) { n = l2; break; }
-        sm.nxt[l] = n;
+        sm.nxt[tid] = n;
     }
     __syncthreads();
     for (int c = tid; c < p.C; c += kThreads)
         if (sm.inv[c] == 0x7fffffff) sm.inv[c] = -1;
+    if (tid < p.SP) sm.dup[tid] = (tid < L && sm.inv[sm.lab[tid]] == tid && sm.nxt[tid] >= 0) ? 1 : 0;
+}
 
-    // P1
-    switch (ch) {
-        case 1: rows_emit<1>(p, sm, b, Tb, L); break;
-        case 2: rows_emit<2>(p, sm, b, Tb, L); break;
-        case 3: rows_emit<3>(p, sm, b, Tb, L); break;
-        case 4: rows_emit<4>(p, sm, b, Tb, L); break;
-        default: rows_emit_generic(p, sm, b, Tb, L); break;
+// diagnostic builds only (CTC_AMD_DEBUG_STOP < 0); never executes in a normal run
+__device__ __forceinline__ void stamp(const NoblankParams &p, int slot)
+{
+    if (p.stop >= 0) return;
+    if (blockIdx.x == 0 && wave_id() == -p.stop - 1 && lane_id() == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
+        o[0] = __builtin_amdgcn_s_memtime();
+        o[1] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+template <int K, int CH>   // CH = 0: generic rows (C > 256)
+__global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p)
+{
+    extern __shared__ float4 smem_raw[];
+    const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C);
+    const int b = blockIdx.x, tid = threadIdx.x, w = wave_id();
+    constexpr int CHR = CH > 0 ? CH : 1;
+    Rows<CHR> rows;
+
+    // loads first, oldest = needed first (vmcnt retires in order): the two lengths, this
+    // thread's label, then the wave's rows of x -- the label tables are built while the
+    // rows are still in flight
+    stamp(p, 0);
+    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
+    const int raw_label = tid < p.S ? load_label(p.lab, p.lab64, (int64_t)b * p.S + tid) : 0;
+    if (CH > 0) rows.load(p, b, w * kRows, p.T);
+
+    // contract: 1 <= L_b <= S, L_b <= T_b <= T (the dataset guarantees it,
+    // charades_ctc_next_pred.py:609-610); anything else has no alignment.
+    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
+    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
+
+    build_label_tables(p, sm, raw_label, L);
+    if (tid < 8) sm.dummy[tid] = 0.f;
+    for (int i = tid; i < kPrefetch * p.SP; i += kThreads) {          // pad rows of em
+        sm.em[i - kPrefetch * p.SP] = kNeg;
+        sm.em[p.T * p.SP + i] = kNeg;
+    }
+    if (p.stop == 1) return;
+    stamp(p, 1);
+
+    // P1 (passes beyond the first are processed first so that pass 0 stays resident)
+    if (CH > 0) {
+        for (int base = ((Tb - 1) / kRowsPerPass) * kRowsPerPass; base > 0; base -= kRowsPerPass) {
+            Rows<CHR> extra;
+            extra.load(p, b, base + w * kRows, Tb);
+            extra.emit(p, sm, base + w * kRows, Tb, L);
+        }
+        rows.emit(p, sm, w * kRows, Tb, L);
+    } else {
+        rows_emit_generic(p, sm, b, Tb, L);
+    }
+    stamp(p, 2);
     __syncthreads();
+    if (p.stop == 2) return;
+    stamp(p, 3);
 
     // P2
-    const int w = wave_id();
     if (Tb > 0) {
-        if (w == 0) lattice_chain<K, true>(sm.em, sm.al, Tb, L, p.SP);
-        else if (w == 1 && p.grad) lattice_chain<K, false>(sm.em, sm.be, Tb, L, p.SP);
+        const bool rot = p.SP <= 63 * K;
+        if (w == 0) {
+            if (rot) lattice_chain<K, true, true>(sm.em, sm.al, sm.dummy, Tb, L, p.SP);
+            else lattice_chain<K, true, false>(sm.em, sm.al, sm.dummy, Tb, L, p.SP);
+        } else if (w == 1 && p.grad) {
+            if (rot) lattice_chain<K, false, true>(sm.em, sm.be, sm.dummy, Tb, L, p.SP);
+            else lattice_chain<K, false, false>(sm.em, sm.be, sm.dummy, Tb, L, p.SP);
+        }
     }
+    stamp(p, 4);
     __syncthreads();
+    if (p.stop == 3) return;
+    stamp(p, 5);
 
     const float nll = ok ? -sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;   // readout, :58-68,139
-    if (w == 0)
+    // published by the LAST wave: it owns the fewest rows (none when T <= 150), so the
+    // store-drain + ticket round trip stays off the other waves' critical path
+    if (w == kWaves - 1)
         publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
                            [](float v, int) { return v; });
     if (!p.grad) return;
@@ -254,18 +320,35 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
     // P3
     const bool feasible = ok && nll < kInfeasible;
     const int Tlive = feasible ? Tb : 0;
-    for (int i = tid; i < Tlive * p.SP; i += kThreads) {
-        const int l = i % p.SP;
-        sm.be[i] = (l < L) ? __expf(sm.al[i] + sm.be[i] - sm.em[i] + nll) : 0.f;
+    if (CH > 0) {
+        const int lane = lane_id();
+        int first[CHR];
+#pragma unroll
+        for (int j = 0; j < CHR; ++j) {
+            const int c = lane + 64 * j;
+            first[j] = (c < p.C) ? sm.inv[c] : -1;
+        }
+        const int G = posterior_group(p.SP), per = kWave / G, sub = lane / G;
+        for (int base = 0; base < p.T; base += kRowsPerPass) {
+            const int t0 = base + w * kRows;
+            for (int r = 0; r < kRows; r += per)             // this wave's own rows: wave-local
+                if (t0 + r < Tlive)
+                    posterior_row(sm.al, sm.be, sm.em, sm.nxt, sm.dup, t0 + r + sub,
+                                  r + sub < kRows && t0 + r + sub < Tlive, L, p.SP, G);
+            if (p.stop == 4) continue;
+            stamp(p, 6);
+            if (base == 0) {
+                rows.grad(p, sm, b, t0, Tlive, first);
+            } else {
+                Rows<CHR> extra;
+                extra.load(p, b, t0, Tlive);
+                extra.grad(p, sm, b, t0, Tlive, first);
+            }
+        }
+    } else {
+        rows_grad_generic(p, sm, b, Tlive, L);
     }
-    __syncthreads();
-    switch (ch) {
-        case 1: rows_grad<1>(p, sm, b, Tlive); break;
-        case 2: rows_grad<2>(p, sm, b, Tlive); break;
-        case 3: rows_grad<3>(p, sm, b, Tlive); break;
-        case 4: rows_grad<4>(p, sm, b, Tlive); break;
-        default: rows_grad_generic(p, sm, b, Tlive); break;
-    }
+    stamp(p, 7);
 }
 
 __global__ __launch_bounds__(256) void scale_grad_kernel(float *g, const float *go, size_t n)
@@ -288,6 +371,19 @@ __global__ __launch_bounds__(256) void scale_grad_kernel(float *g, const float *
     }
 }
 
+template <int K>
+static int launch_noblank(int ch, size_t smem, hipStream_t s, const NoblankParams &p)
+{
+    const dim3 grid(p.B), block(kThreads);
+    switch (ch) {
+        case 1: return launch<noblank_fused_kernel<K, 1>>(grid, block, smem, s, p);
+        case 2: return launch<noblank_fused_kernel<K, 2>>(grid, block, smem, s, p);
+        case 3: return launch<noblank_fused_kernel<K, 3>>(grid, block, smem, s, p);
+        case 4: return launch<noblank_fused_kernel<K, 4>>(grid, block, smem, s, p);
+        default: return launch<noblank_fused_kernel<K, 0>>(grid, block, smem, s, p);
+    }
+}
+
 }  // namespace ctc
 
 using namespace ctc;
@@ -303,25 +399,27 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     if (!x || !labels || !in_len || !tgt_len || !nll || !loss || !workspace) return CTC_AMD_ERR_BAD_ARGUMENT;
     if (T < 1 || B < 1 || C < 1 || S < 1) return CTC_AMD_ERR_BAD_ARGUMENT;
     int K = 1;
-    while (K <= 8 && S > kWave * K) K *= 2;
-    if (K > 8) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    while (K <= 4 && S > kWave * K) K *= 2;
+    if (K > 4) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;         // S <= 256
     NoblankParams p;
     p.x = x; p.st = stride_t; p.sb = stride_b;
     p.lab = labels; p.lab64 = labels_i64;
     p.in_len = in_len; p.tgt_len = tgt_len;
     p.T = T; p.B = B; p.C = C; p.S = S;
     p.SP = (S + K - 1) / K * K;
+    static const int debug_stop = getenv("CTC_AMD_DEBUG_STOP") ? atoi(getenv("CTC_AMD_DEBUG_STOP")) : 0;
+    p.stop = debug_stop;
     p.loss_scale = loss_scale; p.grad_scale = grad_scale;
     p.nll = nll; p.loss = loss; p.grad = grad;
     p.counter = static_cast<unsigned *>(workspace);
     const size_t smem = noblank_smem_bytes(T, p.SP, C);
     if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int ch = C <= 256 ? (C + kWave - 1) / kWave : 0;
     switch (K) {
-        case 1: return launch<noblank_fused_kernel<1>>(dim3(B), dim3(kThreads), smem, s, p);
-        case 2: return launch<noblank_fused_kernel<2>>(dim3(B), dim3(kThreads), smem, s, p);
-        case 4: return launch<noblank_fused_kernel<4>>(dim3(B), dim3(kThreads), smem, s, p);
-        default: return launch<noblank_fused_kernel<8>>(dim3(B), dim3(kThreads), smem, s, p);
+        case 1: return launch_noblank<1>(ch, smem, s, p);
+        case 2: return launch_noblank<2>(ch, smem, s, p);
+        default: return launch_noblank<4>(ch, smem, s, p);
     }
 }
 

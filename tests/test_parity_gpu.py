@@ -113,7 +113,9 @@ def test_noblank_config2_full_size(dev):
     r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
     ref32 = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float32, threads=8)
     ref64 = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64, threads=8)
-    assert_close(r, ref32, 2e-6)
+    # nll: the float32 oracle keeps the reference's rounding sequence; gradient: float64
+    # (the float32 oracle's own exp(alpha+beta+nll) is only good to ~1e-3 relative)
+    assert (np.abs(r["nll"] - ref32["nll"]) <= NLL_RTOL * np.abs(ref32["nll"])).all()
     assert_close(r, ref64, 2e-6)
     # properties that hold at any size: every live row of the gradient sums to zero
     # (softmax minus a distribution), dead rows are zero, mean of nll is the loss

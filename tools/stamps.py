@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle stamps of workgroup 0 of the fused no-blank kernel.
+
+    CTC_AMD_DEBUG_STOP=-1 python tools/stamps.py     # wave 0 (alpha chain wave)
+    CTC_AMD_DEBUG_STOP=-3 python tools/stamps.py     # wave 2 (a rows-only wave)
+Prints shader-clock cycles and 100-MHz realtime ticks between phase boundaries and the
+clock they imply.  Not part of the product path.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+
+wl = bench.Workload("noblank", 256, 256, torch.device("cuda:0"), 0)
+ws = wl.new_workspace()
+loss = torch.zeros(4, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+for _ in range(200):
+    wl.fused(loss.data_ptr(), ws, s)
+torch.cuda.synchronize()
+st = ws.cpu().numpy()[64:64 + 8 * 16].view(np.uint64).reshape(8, 2).astype(np.int64)
+names = ["entry", "tables built", "rows emitted", "barrier1", "chain done", "barrier2", "posteriors", "end"]
+for i in range(1, 8):
+    dc, dr = st[i] - st[i - 1]
+    print("%-14s +%7d cyc  +%6.2f us   (%.2f GHz)" % (names[i], dc, dr / 100.0, dc / max(dr, 1) / 10.0))
+dc, dr = st[7] - st[0]
+print("%-14s  %7d cyc   %6.2f us   (%.2f GHz)" % ("total", dc, dr / 100.0, dc / max(dr, 1) / 10.0))
