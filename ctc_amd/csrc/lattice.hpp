@@ -104,6 +104,7 @@ __device__ __forceinline__ void lattice_chain(const float *em, float *out, float
 // Label positions that repeat a class are then folded into the first occurrence
 // (dup[l] != 0 marks a first occurrence that has repeats, nxt[] chains them), so the
 // gradient pass reads ONE value per class.  Wave-local: LDS ops of a wave are in order.
+template <bool FOLD>
 __device__ __forceinline__ void posterior_row(const float *al, float *be, const float *em, const int *nxt,
                                               const int *dup, int t, bool live, int L, int SP, int G)
 {
@@ -130,7 +131,7 @@ __device__ __forceinline__ void posterior_row(const float *al, float *be, const 
             for (int l = ll; l < SP; l += G)
                 be[off + l] = (l < L) ? fast_exp(al[off + l] + be[off + l] - em[off + l] - m) * inv : 0.f;
     }
-    if (live)
+    if (FOLD && live)
         for (int l = ll; l < L; l += G)
             if (dup[l]) {
                 float tot = be[off + l];

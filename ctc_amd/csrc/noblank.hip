@@ -188,7 +188,7 @@ __device__ __forceinline__ void rows_grad_generic(const NoblankParams &p, const 
     const int lane = lane_id();
     const int G = posterior_group(p.SP), per = kWave / G, sub = lane / G;
     for (int t0 = wave_id() * per; t0 < Tlive; t0 += kWaves * per)
-        posterior_row(sm.al, sm.be, sm.em, sm.nxt, sm.dup, t0 + sub, t0 + sub < Tlive, L, p.SP, G);
+        posterior_row<true>(sm.al, sm.be, sm.em, sm.nxt, sm.dup, t0 + sub, t0 + sub < Tlive, L, p.SP, G);
     __syncthreads();
     for (int t = wave_id(); t < p.T; t += kWaves) {
         const float *row = row_ptr(p, t, b);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
             const int t0 = base + w * kRows;
             for (int r = 0; r < kRows; r += per)             // this wave's own rows: wave-local
                 if (t0 + r < Tlive)
-                    posterior_row(sm.al, sm.be, sm.em, sm.nxt, sm.dup, t0 + r + sub,
+                    posterior_row<true>(sm.al, sm.be, sm.em, sm.nxt, sm.dup, t0 + r + sub,
                                   r + sub < kRows && t0 + r + sub < Tlive, L, p.SP, G);
             if (p.stop == 4) continue;
             stamp(p, 6);

@@ -141,3 +141,60 @@ def test_noblank_infeasible_and_deterministic(dev):
     ok = [0, 1, 3]
     assert np.abs(r1["nll"][ok] - ref["nll"][ok]).max() < 1e-4
     assert np.abs(r1["grad"][:, ok] - ref["grad"][:, ok]).max() < 1e-6
+
+
+# ------------------------------------------------------------------ binary
+@pytest.mark.parametrize("name", ["kat2_binary", "cfg1_binary", "charades_binary", "edge_binary"])
+def test_binary_golden(golden, dev, name):
+    import ctc_amd
+    d = golden(name)
+    r = run_hip(ctc_amd.binary_ctc_loss, d["x"], d["y"], d["in_len"], d["tgt_len"], dev)
+    assert_close(r, d, 1e-5)
+    for b, tb in enumerate(d["in_len"]):
+        assert np.abs(r["grad"][int(tb):, b]).max(initial=0.0) == 0.0
+
+
+def test_binary_modules_and_function_surface(golden, dev):
+    import ctc_amd
+    d = golden("cfg1_binary")
+    x = torch.tensor(d["x"]).to(dev).requires_grad_(True)
+    y = torch.tensor(d["y"]).to(dev)
+    il, tl = torch.tensor(d["in_len"]).to(dev), torch.tensor(d["tgt_len"]).to(dev)
+    loss = ctc_amd.CTCLoss.apply(x, y, il, tl)              # float [B,S,C] targets -> binary variant
+    loss.backward()
+    assert abs(float(loss) - float(d["loss"])) < 1e-4
+    assert np.abs(np_(x.grad) - d["grad"]).max() < 1e-5
+    x2 = torch.tensor(d["x"]).to(dev).requires_grad_(True)
+    loss2 = ctc_amd.NoBlankBinaryCTC()(x2, y, il.cpu(), tl.cpu())
+    (0.5 * loss2).backward()
+    assert np.abs(np_(x2.grad) - 0.5 * d["grad"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(20, 4, 10, 5), (10, 10, 33, 10), (37, 5, 64, 7), (16, 3, 65, 16),
+                                   (50, 6, 200, 50), (40, 3, 300, 12), (60, 2, 40, 100), (150, 8, 158, 20)])
+@pytest.mark.parametrize("var_T", [False, True])
+def test_binary_vs_oracle_shapes(dev, shape, var_T):
+    import ctc_amd
+    T, B, C, S = shape
+    x, y, Tb, L = synth_binary(sum(shape), T, B, C, S, var_T=var_T, density=0.1)
+    if T % 2:
+        y = y * torch.rand(y.shape, generator=torch.Generator().manual_seed(1))   # soft targets
+    ref = ctc_c.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float64)
+    r = run_hip(ctc_amd.binary_ctc_loss, x, y, Tb, L, dev)
+    assert_close(r, ref, 2e-7 * max(1.0, 256.0 / B))
+
+
+def test_binary_config3_full_size(dev):
+    import ctc_amd
+    x, y, Tb, L = synth_binary(0, 150, 256, 158, 20)
+    r = run_hip(ctc_amd.binary_ctc_loss, x, y, Tb, L, dev)
+    ref32 = ctc_c.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float32, threads=8)
+    ref64 = ctc_c.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float64, threads=8)
+    assert (np.abs(r["nll"] - ref32["nll"]) <= NLL_RTOL * np.abs(ref32["nll"])).all()
+    assert_close(r, ref64, 1e-7)
+    # large |x| (reference parity domain |x| <= 15: the -100 clamp / p==1 rounding are mimicked)
+    xb = (x * 4).clamp(-15, 15)
+    r = run_hip(ctc_amd.binary_ctc_loss, xb, y, Tb, L, dev)
+    ref32 = ctc_c.binary_ctc(np_(xb), np_(y), np_(Tb), np_(L), np.float32, threads=8)
+    assert (np.abs(r["nll"] - ref32["nll"]) <= 1e-4 * np.abs(ref32["nll"])).all()
+    assert np.abs(r["grad"] - ref32["grad"]).max() < 1e-6
