@@ -115,12 +115,12 @@ def cur_stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def oracle_step(wl, threads, want_grad=True):
+def oracle_step(wl, threads, want_grad=True, dtype=np.float32):
     from oracle import ctc_c
     from tests.helpers import np_
     x, tg, il, tl = (np_(t) for t in wl.host)
     fn = {"noblank": ctc_c.noblank_ctc, "binary": ctc_c.binary_ctc, "blank": ctc_c.blank_ctc}[wl.variant]
-    return fn(x, tg, il, tl, np.float32, threads=threads, want_grad=want_grad)
+    return fn(x, tg, il, tl, dtype, threads=threads, want_grad=want_grad)
 
 
 def cpu_baseline(wl, budget_s):
@@ -273,11 +273,15 @@ def main():
                          "kernel_us_back_to_back": round(b2b_us, 3),
                          "algorithmic_bytes_per_launch": wl.alg_bytes},
         }
-        # parity of THIS batch against the oracle (cheap, untimed)
-        ref = oracle_step(wl, threads=min(8, os.cpu_count() or 1))
+        # parity of THIS batch against the float64 oracle (untimed)
+        ref = oracle_step(wl, threads=min(16, os.cpu_count() or 1), dtype=np.float64)
         torch.cuda.synchronize()
-        out["parity"] = {"max_abs_err_nll": float(np.abs(wl.nll.cpu().numpy() - ref["nll"]).max()),
+        nll_dev = wl.nll.cpu().numpy().astype(np.float64)
+        out["parity"] = {"checker": "oracle/ctc_oracle.c float64",
+                         "max_rel_err_nll": float((np.abs(nll_dev - ref["nll"]) / np.maximum(1.0, np.abs(ref["nll"]))).max()),
+                         "max_abs_err_nll": float(np.abs(nll_dev - ref["nll"]).max()),
                          "max_abs_err_grad": float(np.abs(wl.grad.cpu().numpy() - ref["grad"] * (1.0 / world)).max())}
+        del ref
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         else:

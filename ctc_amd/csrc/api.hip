@@ -18,8 +18,11 @@ extern "C" size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int 
     // [0,256): arrival counter of the in-launch batch reduction (+ padding)
     size_t bytes = 256;
     if (variant == CTC_AMD_BLANK) {
-        // alpha and beta lattices [B][T][2S+1] fp32
-        bytes += 2 * (size_t)B * (size_t)T * (size_t)(2 * S + 1) * sizeof(float);
+        // emissions, alpha, beta lattices [B][T][NSP] fp32 + three [B][NSP] int state tables;
+        // NSP = 2S+1 padded to 64*K states (K = 2, 4, 8 states per lane), see blank.hip
+        const size_t ns = 2 * (size_t)S + 1;
+        const size_t nsp = ns <= 128 ? 128 : (ns <= 256 ? 256 : 512);
+        bytes += 3 * (size_t)B * (size_t)T * nsp * sizeof(float) + 3 * (size_t)B * nsp * sizeof(int);
     }
     (void)C;
     return bytes;

@@ -198,3 +198,61 @@ def test_binary_config3_full_size(dev):
     ref32 = ctc_c.binary_ctc(np_(xb), np_(y), np_(Tb), np_(L), np.float32, threads=8)
     assert (np.abs(r["nll"] - ref32["nll"]) <= 1e-4 * np.abs(ref32["nll"])).all()
     assert np.abs(r["grad"] - ref32["grad"]).max() < 1e-6
+
+
+# ------------------------------------------------------------------ blank CTC (config 5 semantics)
+def _torch_ctc(lp, tgt, Tb, L):
+    """nll from torch fp32; gradient from torch float64: torch's fp32 backward evaluates
+    exp(alpha+beta+nll-lp) at magnitudes of ~1e3, which is only good to ~3e-4 relative
+    (measured 1.6e-4 abs at T=200, L=1) -- the HIP path normalises per lattice row instead."""
+    lpc = lp.double().clone().requires_grad_(True)
+    loss = torch.nn.functional.ctc_loss(lpc, tgt, Tb, L, blank=0, reduction="mean", zero_infinity=False)
+    loss.backward()
+    nll = torch.nn.functional.ctc_loss(lp, tgt, Tb, L, blank=0, reduction="none")
+    return {"loss": float(loss), "nll": np_(nll), "grad": np_(lpc.grad)}
+
+
+@pytest.mark.parametrize("name", ["blank_small", "blank_long"])
+def test_blank_golden(golden, dev, name):
+    import ctc_amd
+    d = golden(name)
+    r = run_hip(ctc_amd.blank_ctc_loss, d["lp"], d["tgt"], d["in_len"], d["tgt_len"], dev)
+    assert_close(r, d, 1e-5)
+    m = ctc_amd.BlankCTC(blank=0)
+    lp = torch.tensor(d["lp"]).to(dev).requires_grad_(True)
+    loss = m(lp, torch.tensor(d["tgt"]).to(dev), torch.tensor(d["in_len"]), torch.tensor(d["tgt_len"]))
+    loss.backward()
+    assert abs(float(loss) - float(d["loss"])) < 1e-4 and np.abs(np_(lp.grad) - d["grad"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(21, 2, 16, 5), (50, 4, 20, 8), (30, 3, 7, 30), (64, 5, 300, 31),
+                                   (90, 3, 40, 63), (120, 2, 50, 64), (200, 2, 1000, 100), (300, 2, 30, 140)])
+@pytest.mark.parametrize("var_T", [False, True])
+def test_blank_vs_torch_cpu(dev, shape, var_T):
+    """the third-party arithmetic itself (torch CPU F.ctc_loss) is the comparator here"""
+    import ctc_amd
+    T, B, C, S = shape
+    lp, tgt, Tb, L = synth_blank(sum(shape), T, B, C, S, var_T=var_T)
+    if not var_T:
+        tgt[0, 1:4] = tgt[0, 0]                   # repeated labels force blanks in between
+        L[0] = min(S, max(int(L[0]), 4))
+        L[-1] = 1
+    feasible = [b for b in range(B) if int(Tb[b]) >= int(L[b]) + int((tgt[b, 1:int(L[b])] == tgt[b, :int(L[b]) - 1]).sum())]
+    ref = _torch_ctc(lp, tgt, Tb, L)
+    r = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
+    assert len(feasible) >= 1
+    fb = np.array(feasible)
+    assert (np.abs(r["nll"][fb] - ref["nll"][fb]) <= 1e-5 * np.maximum(1, np.abs(ref["nll"][fb]))).all()
+    assert np.abs(r["grad"][:, fb] - ref["grad"][:, fb]).max() < 2e-6 * max(1.0, 64.0 / B)
+    for b in range(B):
+        if b not in feasible:
+            assert np.isinf(r["nll"][b]) and np.isinf(ref["nll"][b])
+            assert np.abs(r["grad"][:, b]).max() == 0.0     # documented: zero, where torch gives NaN
+
+
+def test_blank_int32_targets_and_oracle(dev):
+    import ctc_amd
+    lp, tgt, Tb, L = synth_blank(3, 80, 6, 25, 12, var_T=True)
+    ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64)
+    r = run_hip(ctc_amd.blank_ctc_loss, lp, tgt.int(), Tb, L, dev)
+    assert_close(r, ref, 1e-6)
