@@ -126,8 +126,9 @@ def oracle_step(wl, threads, want_grad=True, dtype=np.float32):
 def cpu_baseline(wl, budget_s):
     """The oracle (C port of the reference arithmetic) on the host cores, bounded sample."""
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nthr = min(ncpu, 16)                                   # the 1-GPU box's CPU share
     out = {}
-    for label, th in (("1", 1), ("all", ncpu)):
+    for label, th in (("1", 1), ("all", nthr)):
         oracle_step(wl, th)                                # warm (thread pool, page faults)
         n, t0 = 0, time.perf_counter()
         while True:

@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 evidence for the bench numbers (run on the GPU box from the repo root):
+#   kernel-trace stats, then separate PMC passes for FETCH_SIZE and WRITE_SIZE
+#   (they do not fit one pass: TCC has 4 slots, FETCH_SIZE takes 3, WRITE_SIZE 2).
+# usage: tools/profile.sh <outdir> <bench args...>
+set -u
+OUT=$(realpath -m "$1"); shift
+REPO=$(pwd)
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $REPO/bench.py --launch eager --steps 50 --warmup 10 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/bench_write.json" 2> "$OUT/write.err"
+# calibration of FETCH_SIZE for this access pattern: the same kernel stopped after the row
+# loads (reads x once = 4*T*B*C bytes, writes nothing)
+CTC_AMD_DEBUG_STOP=2 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_cal" -- $BENCH > /dev/null 2> "$OUT/fetch_cal.err"
+# cross-check of the read side from the raw request-size counters
+rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d "$OUT/pmc_rdreq" -- $BENCH > /dev/null 2> "$OUT/rdreq.err"
+find "$OUT" -name "*.csv" | head -20
