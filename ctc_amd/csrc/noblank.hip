@@ -52,7 +52,7 @@ constexpr int kRowsPerPass = kWaves * kRows;
 
 struct NoblankSmem {
     float *em, *al, *be, *mx, *ls, *dummy;
-    int *lab, *nxt, *dup, *inv;
+    int *cnt, *lab, *nxt, *dup, *inv;
     __device__ NoblankSmem(float *base, int T, int SP, int C)
     {
         em = base + kPrefetch * SP;                     // pad rows on both sides (lattice.hpp)
@@ -61,7 +61,8 @@ struct NoblankSmem {
         mx = be + (size_t)T * SP;
         ls = mx + T;
         dummy = ls + T;
-        lab = reinterpret_cast<int *>(dummy + 8);
+        cnt = reinterpret_cast<int *>(dummy + 8);            // 16 progress counters (pipelined kernel)
+        lab = cnt + 16;
         nxt = lab + SP;
         dup = nxt + SP;
         inv = dup + SP;
@@ -70,7 +71,7 @@ struct NoblankSmem {
 
 static size_t noblank_smem_bytes(int T, int SP, int C)
 {
-    return ((size_t)(3 * T + 2 * kPrefetch) * SP + 2 * (size_t)T + 8 + 3 * (size_t)SP + C + 4) * 4;
+    return ((size_t)(3 * T + 2 * kPrefetch) * SP + 2 * (size_t)T + 8 + 16 + 3 * (size_t)SP + C + 4) * 4;
 }
 
 __device__ __forceinline__ const float *row_ptr(const NoblankParams &p, int t, int b)
@@ -351,6 +352,12 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
     stamp(p, 7);
 }
 
+}  // namespace ctc
+
+#include "noblank_pipe.hpp"
+
+namespace ctc {
+
 __global__ __launch_bounds__(256) void scale_grad_kernel(float *g, const float *go, size_t n)
 {
     const float s = *go;
@@ -416,6 +423,17 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int ch = C <= 256 ? (C + kWave - 1) / kWave : 0;
+    // common case (S <= 64, C <= 256, T <= 168): the pipelined schedule
+    static const bool no_pipe = getenv("CTC_AMD_NOPIPE") != nullptr;
+    if (K == 1 && ch >= 1 && T <= kPipeMaxT && !no_pipe) {
+        const dim3 grid(B), block(kThreads);
+        switch (ch) {
+            case 1: return launch<noblank_pipelined_kernel<1>>(grid, block, smem, s, p);
+            case 2: return launch<noblank_pipelined_kernel<2>>(grid, block, smem, s, p);
+            case 3: return launch<noblank_pipelined_kernel<3>>(grid, block, smem, s, p);
+            default: return launch<noblank_pipelined_kernel<4>>(grid, block, smem, s, p);
+        }
+    }
     switch (K) {
         case 1: return launch_noblank<1>(ch, smem, s, p);
         case 2: return launch_noblank<2>(ch, smem, s, p);

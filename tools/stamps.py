@@ -22,10 +22,12 @@ s = torch.cuda.current_stream().cuda_stream
 for _ in range(200):
     wl.fused(loss.data_ptr(), ws, s)
 torch.cuda.synchronize()
+ws[64:].zero_()
+wl.fused(loss.data_ptr(), ws, s)
+torch.cuda.synchronize()
 st = ws.cpu().numpy()[64:64 + 8 * 16].view(np.uint64).reshape(8, 2).astype(np.int64)
-names = ["entry", "tables built", "rows emitted", "barrier1", "chain done", "barrier2", "posteriors", "end"]
-for i in range(1, 8):
-    dc, dr = st[i] - st[i - 1]
-    print("%-14s +%7d cyc  +%6.2f us   (%.2f GHz)" % (names[i], dc, dr / 100.0, dc / max(dr, 1) / 10.0))
-dc, dr = st[7] - st[0]
-print("%-14s  %7d cyc   %6.2f us   (%.2f GHz)" % ("total", dc, dr / 100.0, dc / max(dr, 1) / 10.0))
+print("slot: us since entry (slots mean different things per kernel/wave, see the kernel source)")
+for i in range(8):
+    if st[i][1] > 0:
+        print("  slot %d: %7.2f us  %8d cyc" % (i, (st[i][1] - st[0][1]) / 100.0, st[i][0] - st[0][0]))
+
