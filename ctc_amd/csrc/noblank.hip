@@ -427,11 +427,25 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     static const bool no_pipe = getenv("CTC_AMD_NOPIPE") != nullptr;
     if (K == 1 && ch >= 1 && T <= kPipeMaxT && !no_pipe) {
         const dim3 grid(B), block(kThreads);
+        static const int cus = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess)
+                (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n;
+        }();
+        if (B > cus && 2 * smem <= kMaxLds) {                // more samples than CUs: two workgroups per CU
+            switch (ch) {
+                case 1: return launch<noblank_pipelined_kernel<1, true>>(grid, block, smem, s, p);
+                case 2: return launch<noblank_pipelined_kernel<2, true>>(grid, block, smem, s, p);
+                case 3: return launch<noblank_pipelined_kernel<3, true>>(grid, block, smem, s, p);
+                default: return launch<noblank_pipelined_kernel<4, true>>(grid, block, smem, s, p);
+            }
+        }
         switch (ch) {
-            case 1: return launch<noblank_pipelined_kernel<1>>(grid, block, smem, s, p);
-            case 2: return launch<noblank_pipelined_kernel<2>>(grid, block, smem, s, p);
-            case 3: return launch<noblank_pipelined_kernel<3>>(grid, block, smem, s, p);
-            default: return launch<noblank_pipelined_kernel<4>>(grid, block, smem, s, p);
+            case 1: return launch<noblank_pipelined_kernel<1, false>>(grid, block, smem, s, p);
+            case 2: return launch<noblank_pipelined_kernel<2, false>>(grid, block, smem, s, p);
+            case 3: return launch<noblank_pipelined_kernel<3, false>>(grid, block, smem, s, p);
+            default: return launch<noblank_pipelined_kernel<4, false>>(grid, block, smem, s, p);
         }
     }
     switch (K) {

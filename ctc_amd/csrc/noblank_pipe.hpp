@@ -141,8 +141,11 @@ __device__ __forceinline__ float lattice_chain_sync(const NoblankParams &p, cons
     return a;
 }
 
-template <int CH>
-__global__ __launch_bounds__(kThreads) void noblank_pipelined_kernel(NoblankParams p)
+// DUAL: cap the kernel at 64 VGPRs (8 waves/SIMD) so that TWO 16-wave workgroups share a CU.
+// With more samples than CUs their phases then interleave (one streams while the other
+// scans); with one workgroup per CU the uncapped build (66 VGPRs, no scratch) is faster.
+template <int CH, bool DUAL>
+__global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kernel(NoblankParams p)
 {
     extern __shared__ float4 smem_raw[];
     const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C);
