@@ -16,6 +16,8 @@
 // t = w, w+16, ...: elementwise lp/lq into a wave-private LDS row, then S dot products
 // (lanes over c, DPP wave reduction).  Chains and posteriors as in noblank.hip.  The
 // gradient pass contracts gamma_t with the staged y per element and re-reads x (L2).
+#include <cstdlib>
+
 #include "lattice.hpp"
 #include "launch.hpp"
 
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_fused_kernel(BinaryParams 
 {
     extern __shared__ float4 smem_raw[];
     const BinarySmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.S, p.CP);
-    const int b = blockIdx.x, tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
     const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
     const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
     const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
@@ -160,6 +162,197 @@ __global__ __launch_bounds__(kBinThreads) void binary_fused_kernel(BinaryParams 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// MFMA variant (the fast path when the images fit in LDS).  Both contractions are real
+// [T x C].[C x S] GEMMs (0.95 MFLOP per sample each way), so this is the one place on the
+// CTC path where the matrix cores are the right tool: v_mfma_f32_16x16x4_f32 is exact fp32
+// (a k-ordered fmaf chain) at the fp32 vector rate, needs no cross-lane reduction and
+// leaves the VALU to the elementwise work.
+//
+//   P1a every wave: its kBinRows rows of x (kept in registers for P3c) -> d = lp - lq into an
+//       LDS image D[t][c] (pitch PD), Q[t] = sum_c lq by a DPP reduction
+//   P1b E = D . Y^T on MFMA: A fragment = D[16m + (lane&15)][4k + (lane>>4)],
+//       B fragment = Y[16n + (lane&15)][4k + (lane>>4)]; PD = 2 (mod 32) makes both
+//       ds_read_b32 patterns conflict-free; e[t,l] = (E + Q[t]) / C
+//   P2  chains (lattice.hpp)
+//   P3a posteriors per row (gamma, 0 beyond L)      P3b G = gamma . Y on MFMA into the D image
+//   P3c grad[t,c] = scale/C * (sigmoid(x) - G[t,c]) * p(1-p)/max(p(1-p),1e-12) from the
+//       resident rows, coalesced stores
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBinRows = 160 / kBinWaves;                    // rows resident per wave (T <= 160)
+
+struct BinaryMfmaSmem {
+    float *em, *al, *be, *dummy, *q, *ys, *dimg;
+    __device__ BinaryMfmaSmem(float *base, int T, int Tpad, int SP, int PD)
+    {
+        em = base + kPrefetch * SP;
+        al = em + (size_t)(T + kPrefetch) * SP;
+        be = al + (size_t)T * SP;
+        dummy = be + (size_t)T * SP;
+        q = dummy + 8;
+        ys = q + Tpad;
+        dimg = ys + (size_t)SP * PD;
+    }
+};
+
+static size_t binary_mfma_smem_bytes(int T, int Tpad, int SP, int PD)
+{
+    return ((size_t)(3 * T + 2 * kPrefetch) * SP + 8 + Tpad + (size_t)SP * PD + (size_t)Tpad * PD) * 4;
+}
+
+template <int K, int CH>
+__global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p, int Tpad, int PD)
+{
+    extern __shared__ float4 smem_raw[];
+    const BinaryMfmaSmem sm(reinterpret_cast<float *>(smem_raw), p.T, Tpad, p.SP, PD);
+    const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
+
+    // rows of this wave, unconditional clamped loads (stay resident until P3c)
+    float v[kBinRows][CH];
+#pragma unroll
+    for (int r = 0; r < kBinRows; ++r) {
+        const int t = w * kBinRows + r;
+        const float *row = p.x + (int64_t)(t < p.T ? t : p.T - 1) * p.st + (int64_t)b * p.sb;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c = lane + 64 * j;
+            v[r][j] = row[c < p.C ? c : p.C - 1];
+        }
+    }
+    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
+    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
+
+    // y[b] -> LDS image [SP][PD], zero beyond S rows / C columns (MFMA K and N padding)
+    const float *yb = p.y + (int64_t)b * p.S * p.C;
+    for (int i = tid; i < p.SP * PD; i += kBinThreads) {
+        const int l = i / PD, c = i - l * PD;
+        sm.ys[i] = (l < p.S && c < p.C) ? yb[l * p.C + c] : 0.f;
+    }
+    if (tid < 8) sm.dummy[tid] = 0.f;
+    for (int i = tid; i < kPrefetch * p.SP; i += kBinThreads) {
+        sm.em[i - kPrefetch * p.SP] = kNeg;
+        sm.em[p.T * p.SP + i] = kNeg;
+    }
+
+    // P1a: elementwise BCE logs -> D image, Q
+#pragma unroll
+    for (int r = 0; r < kBinRows; ++r) {
+        const int t = w * kBinRows + r;
+        if (t >= Tpad) break;                                // wave-uniform
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c = lane + 64 * j;
+            float pr, lp, lq;
+            bce_logs(v[r][j], pr, lp, lq);
+            const bool in = c < p.C && t < Tb;
+            if (c < PD) sm.dimg[t * PD + c] = in ? lp - lq : 0.f;    // zero K padding / dead rows
+            q += in ? lq : 0.f;
+        }
+        q = wave_sum(q);
+        if (lane == 0) sm.q[t] = q;
+    }
+    __syncthreads();
+
+    // P1b: E = D . Y^T (16x16 tiles, K = C in steps of 4)
+    const int MT = Tpad >> 4, NT = (p.SP + 15) >> 4, KT = (p.C + 3) >> 2;
+    const float invC = 1.0f / (float)p.C;
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int job = w; job < MT * NT; job += kBinWaves) {
+        const int m = job / NT, n = job - m * NT;
+        const int lrow = 16 * n + fr;
+        const float *ap = sm.dimg + (16 * m + fr) * PD + fq;
+        const float *bp = sm.ys + (lrow < p.SP ? lrow : p.SP - 1) * PD + fq;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < KT; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk], bp[4 * kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = 16 * m + 4 * fq + j;
+            if (t < Tb && lrow < p.SP) sm.em[t * p.SP + lrow] = lrow < L ? (acc[j] + sm.q[t]) * invC : kNeg;
+        }
+    }
+    __syncthreads();
+
+    // P2: alpha / beta' chains
+    if (Tb > 0) {
+        const bool rot = p.SP <= 63 * K;
+        if (w == 0) {
+            if (rot) lattice_chain<K, true, true>(sm.em, sm.al, sm.dummy, Tb, L, p.SP);
+            else lattice_chain<K, true, false>(sm.em, sm.al, sm.dummy, Tb, L, p.SP);
+        } else if (w == 1 && p.grad) {
+            if (rot) lattice_chain<K, false, true>(sm.em, sm.be, sm.dummy, Tb, L, p.SP);
+            else lattice_chain<K, false, false>(sm.em, sm.be, sm.dummy, Tb, L, p.SP);
+        }
+    }
+    __syncthreads();
+
+    const float nll = ok ? -sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;
+    if (w == kBinWaves - 1)
+        publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
+                           [](float x, int) { return x; });
+    if (!p.grad) return;
+
+    // P3a: posteriors (rows round-robin over the waves)
+    const bool feasible = ok && nll < kInfeasible;
+    const int Tlive = feasible ? Tb : 0;
+    {
+        const int G = posterior_group(p.SP), per = kWave / G, sub = lane / G;
+        for (int t0 = w * per; t0 < Tlive; t0 += kBinWaves * per)
+            posterior_row<false>(sm.al, sm.be, sm.em, nullptr, nullptr, t0 + sub, t0 + sub < Tlive, L, p.SP, G);
+    }
+    __syncthreads();
+
+    // P3b: G = gamma . Y (M = t, N = c, K = l) into the D image
+    const int NC = (p.C + 15) >> 4, KL = p.SP >> 2;
+    for (int job = w; job < MT * 2; job += kBinWaves) {
+        const int m = job >> 1, half = job & 1;
+        const int n_lo = half ? (NC + 1) / 2 : 0, n_hi = half ? NC : (NC + 1) / 2;
+        const float *ap = sm.be + (16 * m + fr) * p.SP + fq;
+        for (int n = n_lo; n < n_hi; ++n) {
+            const float *bp = sm.ys + fq * PD + 16 * n + fr;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kk = 0; kk < KL; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk], bp[4 * kk * PD], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm.dimg[(16 * m + 4 * fq + j) * PD + 16 * n + fr] = acc[j];
+        }
+    }
+    __syncthreads();
+
+    // P3c: gradient rows from the resident registers
+    const float gs = p.grad_scale * invC;
+#pragma unroll
+    for (int r = 0; r < kBinRows; ++r) {
+        const int t = w * kBinRows + r;
+        if (t >= p.T) break;                                 // wave-uniform
+        float *g = p.grad + ((int64_t)t * p.B + b) * p.C;
+        const bool live = t < Tlive;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c = lane + 64 * j;
+            if (c < p.C) {
+                const float pr = 1.0f / (1.0f + expf(-v[r][j]));
+                const float pq = pr * (1.0f - pr);
+                const float occ = sm.dimg[t * PD + c];
+                g[c] = live ? gs * (pr - occ) * (pq / fmaxf(pq, 1e-12f)) : 0.f;
+            }
+        }
+    }
+}
+
+template <int K>
+static int launch_binary_mfma(int ch, size_t smem, hipStream_t s, const BinaryParams &p, int Tpad, int PD)
+{
+    const dim3 grid(p.B), block(kBinThreads);
+    switch (ch) {
+        case 1: return launch<binary_mfma_kernel<K, 1>>(grid, block, smem, s, p, Tpad, PD);
+        case 2: return launch<binary_mfma_kernel<K, 2>>(grid, block, smem, s, p, Tpad, PD);
+        case 3: return launch<binary_mfma_kernel<K, 3>>(grid, block, smem, s, p, Tpad, PD);
+        default: return launch<binary_mfma_kernel<K, 4>>(grid, block, smem, s, p, Tpad, PD);
+    }
+}
+
 }  // namespace ctc
 
 using namespace ctc;
@@ -186,9 +379,27 @@ extern "C" int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_
     p.loss_scale = loss_scale; p.grad_scale = grad_scale;
     p.nll = nll; p.loss = loss; p.grad = grad;
     p.counter = static_cast<unsigned *>(workspace);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // fast path: MFMA contractions, rows resident (T <= 160, C <= 256, images fit in LDS)
+    if (T <= kBinRows * kBinWaves && C <= 256 && !getenv("CTC_AMD_BINARY_VALU")) {
+        BinaryParams q = p;
+        q.SP = (p.SP + 3) / 4 * 4;                           // K padding of the gamma . Y product
+        if (q.SP % K) q.SP = (q.SP + 4 * K - 1) / (4 * K) * (4 * K);
+        const int Tpad = (T + 15) / 16 * 16;
+        int PD = (C + 3) / 4 * 4 + 2;                        // >= C (+K padding), PD = 2 (mod 32):
+        while (PD % 32 != 2) PD += 2;                        // conflict-free MFMA fragment reads
+        const size_t need = binary_mfma_smem_bytes(T, Tpad, q.SP, PD);
+        if (need <= kMaxLds) {
+            const int ch = (C + kWave - 1) / kWave;
+            switch (K) {
+                case 1: return launch_binary_mfma<1>(ch, need, s, q, Tpad, PD);
+                case 2: return launch_binary_mfma<2>(ch, need, s, q, Tpad, PD);
+                default: return launch_binary_mfma<4>(ch, need, s, q, Tpad, PD);
+            }
+        }
+    }
     const size_t smem = binary_smem_bytes(T, p.SP, S, p.CP);
     if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid(B), block(kBinThreads);
     switch (K) {
         case 1: return launch<binary_fused_kernel<1>>(grid, block, smem, s, p);

@@ -15,6 +15,16 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 // wave-uniform by construction: keep it in an SGPR so row indices / LDS row addresses are scalar
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2).  Rows of
+// neighbouring samples share 128-byte lines (a row is C*4 bytes, rarely a multiple of 128),
+// so consecutive samples are mapped onto the SAME XCD: the straddling lines are then fetched
+// from HBM once per XCD instead of once per neighbour.  Bijective for any B; speed only.
+__device__ __forceinline__ int xcd_sample(int bid, int B)
+{
+    const int x = bid & 7, k = bid >> 3, q = B >> 3, r = B & 7;
+    return x * q + (x < r ? x : r) + k;
+}
+
 // lane i <- lane i-1 (lane 0 keeps `fill`): DPP wave_shr:1, one VALU op, no LDS.
 __device__ __forceinline__ float wave_shr1(float v, float fill)
 {

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
 {
     extern __shared__ float4 smem_raw[];
     const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C);
-    const int b = blockIdx.x, tid = threadIdx.x, w = wave_id();
+    const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id();
     constexpr int CHR = CH > 0 ? CH : 1;
     Rows<CHR> rows;
 

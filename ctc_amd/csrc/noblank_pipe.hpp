@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
 {
     extern __shared__ float4 smem_raw[];
     const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C);
-    const int b = blockIdx.x, tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
     const int u = w - 2;                                     // worker index (chain waves: < 0)
     const float ninf = -__builtin_inff();
 

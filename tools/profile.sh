@@ -12,9 +12,6 @@ BENCH="python3 $REPO/bench.py --launch eager --steps 50 --warmup 10 --no-cpu-bas
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/bench_write.json" 2> "$OUT/write.err"
-# calibration of FETCH_SIZE for this access pattern: the same kernel stopped after the row
-# loads (reads x once = 4*T*B*C bytes, writes nothing)
-CTC_AMD_DEBUG_STOP=2 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_cal" -- $BENCH > /dev/null 2> "$OUT/fetch_cal.err"
-# cross-check of the read side from the raw request-size counters
+# exact read bytes from the request-size counters (FETCH_SIZE tallies a 128-B request at 64 B)
 rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d "$OUT/pmc_rdreq" -- $BENCH > /dev/null 2> "$OUT/rdreq.err"
 find "$OUT" -name "*.csv" | head -20

@@ -5,9 +5,10 @@
 
 Traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE come from separate --pmc passes, unit KiB; WRITE_SIZE is exact for streaming
-stores; FETCH_SIZE under-counts wide reads on gfx950, so it is corrected by a factor
-calibrated on THIS access pattern (the same kernel stopped after its row loads, which reads
-exactly `x_bytes`), and cross-checked against the raw 32/64/128-byte request counters.
+stores; on gfx950 FETCH_SIZE = (number of fabric read requests) x 64 B, i.e. it tallies a
+128-byte request at 64 B.  The read side is therefore taken from the request-size counters
+of a third pass (32B x n32 + 64B x n64 + 128B x n128, exact); FETCH_SIZE x 2 (the guide's
+correction for wide streaming reads) is printed beside it.
 """
 import collections
 import csv
@@ -38,30 +39,26 @@ def main():
             float(r["MaxNs"]) / 1e3, r["Percentage"]))
     fetch = per_kernel(os.path.join(src, "pmc_fetch"), want)
     write = per_kernel(os.path.join(src, "pmc_write"), want)
-    cal = per_kernel(os.path.join(src, "pmc_fetch_cal"), want)
     raw = per_kernel(os.path.join(src, "pmc_rdreq"), want)
     lines += ["", "## HBM traffic per launch (PMC, separate passes)", ""]
     out = {}
     for k in fetch:
         fs = fetch[k]["FETCH_SIZE"] * 1024.0
         ws = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
-        cs = cal.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
-        factor = x_bytes / cs if cs else 2.0
         lines += ["kernel `%s`" % k[:90], "",
-                  "* FETCH_SIZE raw = %.0f B; calibration run (reads x once = %.0f B) raw = %.0f B -> correction x%.3f"
-                  % (fs, x_bytes, cs, factor),
-                  "* WRITE_SIZE = %.0f B (exact for streaming stores)" % ws,
-                  "* **traffic = FETCH_SIZE x %.3f + WRITE_SIZE = %.0f B per launch**" % (factor, fs * factor + ws)]
+                  "* FETCH_SIZE raw = %.0f B (x2 = %.0f B)" % (fs, 2 * fs),
+                  "* WRITE_SIZE = %.0f B (exact for streaming stores)" % ws]
+        rd = 2 * fs
         if k in raw:
             r = raw[k]
-            b = 32 * r.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * r.get("TCC_EA0_RDREQ_64B_sum", 0) + \
-                128 * r.get("TCC_EA0_RDREQ_128B_sum", 0)
-            lines.append("* cross-check, raw read requests: 32B x %.0f + 64B x %.0f + 128B x %.0f = %.0f B"
-                         % (r.get("TCC_EA0_RDREQ_32B_sum", 0), r.get("TCC_EA0_RDREQ_64B_sum", 0),
-                            r.get("TCC_EA0_RDREQ_128B_sum", 0), b))
-            out["read_bytes_from_request_counters"] = b
-        out.update({"hbm_bytes_per_launch": round(fs * factor + ws), "fetch_size_raw_bytes": round(fs),
-                    "fetch_correction": round(factor, 4), "write_size_bytes": round(ws), "kernel": k[:120]})
+            n32, n64, n128 = (r.get("TCC_EA0_RDREQ_%s_sum" % w, 0) for w in ("32B", "64B", "128B"))
+            rd = 32 * n32 + 64 * n64 + 128 * n128
+            lines.append("* read requests: 32B x %.0f + 64B x %.0f + 128B x %.0f = %.0f B  "
+                         "(requests x 64 B = %.0f B = FETCH_SIZE)" % (n32, n64, n128, rd, 64 * (n32 + n64 + n128)))
+        lines.append("* **traffic = reads %.0f B + writes %.0f B = %.0f B per launch** (logits once = %.0f B)"
+                     % (rd, ws, rd + ws, x_bytes))
+        out.update({"hbm_bytes_per_launch": round(rd + ws), "read_bytes": round(rd), "write_bytes": round(ws),
+                    "fetch_size_raw_bytes": round(fs), "kernel": k[:120]})
         lines.append("")
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     open(dst + ".md", "w").write("\n".join(lines) + "\n")
