@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--graph-steps", type=int, default=50, help="steps captured per hipGraph")
     ap.add_argument("--loss-bucket", type=int, default=None,
                     help="N>1: steps per RCCL all-reduce of the loss scalars (default = graph-steps, eager: 1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1 collective backend: nccl = RCCL over xGMI; gloo only to rehearse the multi-rank "
+                         "path on a box with fewer GPUs than ranks (ranks then share devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU budget of the oracle baseline leg")
     return ap.parse_args()
@@ -152,12 +155,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (a.gpus, world))
+    ndev = torch.cuda.device_count()
+    if local >= ndev and a.backend == "nccl":
+        raise SystemExit("rank %d has no GPU (%d visible): RCCL needs one GPU per rank" % (local, ndev))
+    local %= max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     variant = a.variant
     B = a.batch or WORKLOADS[variant][4]
@@ -265,6 +275,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.name, "variant": variant, "per_gpu_batch": B, "global_batch": B * world,
                        "T": wl.T, "C": wl.C, "S": wl.S, "parallelism": "dp%d (batch-sharded)" % world,
+                       "collective": (a.backend if world > 1 else None),
                        "launch": a.launch, "graph_steps": M if a.launch == "graph" else None,
                        "loss_allreduce_bucket": bucket if world > 1 else None,
                        "step": "fused loss+grad launch + scale_grad launch (loss.backward(), grad_out=1)"},

@@ -216,3 +216,37 @@ def blank_ctc_loss(log_probs, targets, input_lengths, target_lengths, blank=0, b
     semantics (models/layers/AsyncTFCriterion.py:198): log_probs are normalised
     log-probabilities, loss = mean_b(nll_b / max(L_b,1))."""
     return _LossFn.apply(log_probs, targets, input_lengths, target_lengths, _lib.BLANK, batch_total, blank)
+
+
+def noblank_best_path(logits, targets, input_lengths, target_lengths):
+    """Best (Viterbi) alignment on the no-blank lattice -> (path[B,T] int32, score[B]).
+
+    ``path[b,t]`` is the label POSITION l_t (index into targets[b]) occupied at step t, -1 for
+    ``t >= T_b`` or when no alignment exists; ``score[b]`` its log-probability.  Max-semiring
+    twin of the loss recursion (NoBlankCTC.py:71-87); SURVEY 8(f) rank 1.
+    """
+    _require_hip(logits, "logits")
+    if logits.dim() != 3 or logits.dtype != torch.float32:
+        raise ValueError("ctc_amd: logits must be float32 [T,B,C]")
+    T, B, C = logits.shape
+    dev = logits.device
+    xs = logits.detach()
+    if xs.stride(2) != 1:
+        xs = xs.contiguous()
+    if _variant_of(targets) != _lib.NOBLANK or targets.shape[0] != B:
+        raise ValueError("ctc_amd: targets must be [B,S] integer")
+    if targets.dtype not in (torch.int32, torch.int64):
+        targets = targets.long()
+    tg = targets.to(device=dev, non_blocking=True).contiguous()
+    S = tg.shape[1]
+    il = _lengths(input_lengths, B, "input_lengths", dev, T)
+    tl = _lengths(target_lengths, B, "target_lengths", dev, S)
+    path = torch.empty((B, T), dtype=torch.int32, device=dev)
+    score = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().ctc_amd_noblank_best_path(
+            xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(), int(tg.dtype == torch.int64),
+            il.data_ptr(), tl.data_ptr(), T, B, C, S, path.data_ptr(), score.data_ptr(), None,
+            _stream_handle(dev))
+    _lib.check(rc, "ctc_amd_noblank_best_path")
+    return path, score

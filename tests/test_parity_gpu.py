@@ -256,3 +256,26 @@ def test_blank_int32_targets_and_oracle(dev):
     ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64)
     r = run_hip(ctc_amd.blank_ctc_loss, lp, tgt.int(), Tb, L, dev)
     assert_close(r, ref, 1e-6)
+
+
+# ------------------------------------------------------------------ best path
+@pytest.mark.parametrize("shape", [(20, 4, 10, 5), (150, 16, 158, 20), (40, 3, 300, 12), (90, 2, 40, 70)])
+def test_noblank_best_path(dev, shape):
+    import ctc_amd
+    T, B, C, S = shape
+    x, lab, Tb, L = synth_noblank(sum(shape) + 1, T, B, C, S, var_T=True)
+    path, score = ctc_amd.noblank_best_path(x.to(dev), lab.to(dev), Tb.to(dev), L.to(dev))
+    torch.cuda.synchronize()
+    path, score = np_(path), np_(score)
+    rp, rs = ctc_numpy.noblank_best_path(np_(x), np_(lab), np_(Tb), np_(L))
+    assert np.abs(score - rs).max() <= 1e-5 * np.abs(rs).max()
+    for b in range(B):
+        tb, l = int(Tb[b]), int(L[b])
+        p = path[b]
+        assert (p[tb:] == -1).all() and p[0] == 0 and p[tb - 1] == l - 1
+        d = np.diff(p[:tb])
+        assert ((d == 0) | (d == 1)).all()                      # monotone, one label per step
+    # the returned alignment really attains the optimal score (robust to fp near-ties)
+    got = ctc_numpy.path_score(np_(x), np_(lab), path, np_(Tb))
+    assert np.abs(got - rs).max() <= 1e-4
+    assert (path == rp).mean() > 0.98
