@@ -28,6 +28,10 @@
 namespace ctc {
 
 constexpr int kPipeWorkers = kWaves - 2;
+#ifndef CTC_CHAIN_B
+#define CTC_CHAIN_B 2
+#endif
+constexpr int kChainB = CTC_CHAIN_B;   // wave of the beta' chain: 2 measured 0.4 us faster than 1, 4 slower
 constexpr int kPipeRows = 12;                               // slots per worker
 constexpr int kPipeMaxT = kPipeWorkers * kPipeRows;         // 168
 constexpr int kSpinLimit = 1 << 20;
@@ -150,7 +154,8 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
     extern __shared__ float4 smem_raw[];
     const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    const int u = w - 2;                                     // worker index (chain waves: < 0)
+    // roles: waves 0 and kChainB are the chains, the rest are workers 0..13
+    const int u = (w == 0 || w == kChainB) ? -1 : (w < kChainB ? w - 1 : w - 2);
     const float ninf = -__builtin_inff();
 
     stamp(p, 0);
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
                 const float nll = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), L - 1));
                 publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
                                    [](float x, int) { return x; });
-            } else if (p.grad) {
+            } else if (p.grad) {                             // w == kChainB
                 if (rot) lattice_chain_sync<false, true>(p, sm.em, sm.be, sm.dummy, sm.cnt, p.T, Tb, L, p.SP);
                 else lattice_chain_sync<false, false>(p, sm.em, sm.be, sm.dummy, sm.cnt, p.T, Tb, L, p.SP);
                 stamp(p, 2);
