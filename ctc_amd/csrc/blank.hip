@@ -86,17 +86,24 @@ __global__ __launch_bounds__(256) void blank_gather_kernel(BlankParams p, int ro
     for (int t = t_begin; t < t_end; ++t) {
         const float *row = p.lp + (int64_t)t * p.st + (int64_t)b * p.sb;
         float *out = p.em + ((int64_t)b * p.T + t) * p.NSP;
-        for (int s = tid; s < p.NSP; s += blockDim.x) out[s] = s < n ? fmaxf(row[s_cls[s]], kNegB) : kNegB;
+        for (int s = tid; s < p.NSP; s += blockDim.x) out[s] = s < n ? fmaxf(row[s_cls[s]] * kLog2e, kNegB) : kNegB;
     }
 }
 
 // ---- K1: alpha / beta chains ----------------------------------------------------------------
-__device__ __forceinline__ float lse3(float a, float b, float c)
+// The blank lattice (em, alpha, beta) is kept in LOG2 units: v_exp_f32 / v_log_f32 are base-2,
+// so a state update is max, subtract, exp2, add, log2, add with no base-conversion multiplies.
+// Only differences alpha+beta-em and the final likelihood (x ln 2) leave the lattice.
+__device__ __forceinline__ float lse3_2(float a, float b, float c)
 {
     const float m = fmaxf(fmaxf(a, b), c);
-    const float s = __builtin_amdgcn_exp2f((a - m) * kLog2e) + __builtin_amdgcn_exp2f((b - m) * kLog2e) +
-                    __builtin_amdgcn_exp2f((c - m) * kLog2e);
-    return __builtin_fmaf(__builtin_amdgcn_logf(s), kLn2, m);
+    const float s = __builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) + __builtin_amdgcn_exp2f(c - m);
+    return m + __builtin_amdgcn_logf(s);
+}
+__device__ __forceinline__ float lse2_2(float a, float b)
+{
+    const float m = fmaxf(a, b);
+    return m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(a - b)));
 }
 
 template <int K, bool FWD>
@@ -141,8 +148,10 @@ __device__ __forceinline__ void blank_chain(const BlankParams &p, int b, int Tb,
                 x1 = k + 1 < K ? a[k + 1] : n1;
                 x2 = k + 2 < K ? a[k + 2] : (k + 1 < K ? n1 : n2);
             }
-            const float v = lse3(a[k], x1, skip[k] ? x2 : kNegB) + e[k];
-            nx[k] = valid[k] ? fmaxf(v, kNegB) : kNegB;
+            // s = lane*K + k with K even: k even <=> blank state (two predecessors, no skip).
+            // States beyond n carry the sentinel emission and just sink (stay finite: they lose
+            // 1e30 per step, fp32 holds that for any T); no per-state masking or clamping.
+            nx[k] = ((k & 1) ? lse3_2(a[k], x1, skip[k] ? x2 : kNegB) : lse2_2(a[k], x1)) + e[k];
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) a[k] = nx[k];
@@ -200,8 +209,8 @@ __global__ __launch_bounds__(128) void blank_chain_kernel(BlankParams p)
             }
             v1 = wave_sum(v1);
             v2 = n >= 2 ? wave_sum(v2) : kNegB;
-            const float ll = lse3(v1, v2, kNegB);
-            nll = ll < -1.0e29f ? __builtin_inff() : -ll;
+            const float ll2 = lse2_2(v1, v2);
+            nll = ll2 < -1.0e29f ? __builtin_inff() : -ll2 * kLn2;
         } else if (ok && L == 0) {
             nll = 0.f;                                       // empty input, empty target
         }
@@ -218,14 +227,20 @@ __global__ __launch_bounds__(128) void blank_chain_kernel(BlankParams p)
 // ---- K2: gamma -> gradient rows ----------------------------------------------------------------
 constexpr int kGradWaves = 4;
 
-template <int K>
+// VEC4: C % 4 == 0 and 16-byte aligned rows -> the dense part moves float4 per lane (4x fewer
+// memory instructions); the row's loads are all issued before the reductions so their latency
+// hides behind them.  kMaxV4 float4 per lane cover C <= 1024 in registers.
+constexpr int kMaxV4 = 4;
+
+template <int K, bool VEC4>
 __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankParams p, int total_rows)
 {
-    extern __shared__ float s_buf[];                         // per wave: occ[C] + gam[NSP]
+    extern __shared__ float4 s_buf4[];                       // per wave: occ[C4] + gam[NSP]
     const int w = wave_id(), lane = lane_id();
-    float *occ = s_buf + (size_t)w * (p.C + p.NSP);
-    float *gam = occ + p.C;
-    for (int c = lane; c < p.C; c += kWave) occ[c] = 0.f;
+    const int C4 = (p.C + 3) & ~3;
+    float *occ = reinterpret_cast<float *>(s_buf4) + (size_t)w * (C4 + p.NSP);
+    float *gam = occ + C4;
+    for (int c = lane; c < C4; c += kWave) occ[c] = 0.f;
     const int s0 = lane * K;
     for (int idx = blockIdx.x * kGradWaves + w; idx < total_rows; idx += gridDim.x * kGradWaves) {
         const int t = idx / p.B, b = idx - t * p.B;          // consecutive waves -> consecutive b: contiguous rows
@@ -234,12 +249,26 @@ __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankPar
         float *g = p.grad + ((int64_t)t * p.B + b) * p.C;
         const float nllb = p.nll[b];
         if (!ok || t >= Tb || !(nllb < 3.0e38f)) {           // beyond T_b, or no alignment: zero row
-            for (int c = lane; c < p.C; c += kWave) g[c] = 0.f;
+            if (VEC4) {
+                for (int q = lane; q < (p.C >> 2); q += kWave) reinterpret_cast<float4 *>(g)[q] = make_float4(0, 0, 0, 0);
+            } else {
+                for (int c = lane; c < p.C; c += kWave) g[c] = 0.f;
+            }
             continue;
         }
         const int n = 2 * L + 1;
         const int64_t off = ((int64_t)b * p.T + t) * p.NSP + s0;
         const int *cls = p.cls + b * p.NSP, *nxt = p.nxt + b * p.NSP, *first = p.first + b * p.NSP;
+        const float *row = p.lp + (int64_t)t * p.st + (int64_t)b * p.sb;
+        // all loads of the row first
+        float4 xr[kMaxV4];
+        if (VEC4) {
+#pragma unroll
+            for (int i = 0; i < kMaxV4; ++i) {
+                const int q = lane + kWave * i;
+                xr[i] = q < (p.C >> 2) ? reinterpret_cast<const float4 *>(row)[q] : make_float4(0, 0, 0, 0);
+            }
+        }
         float v[K];
         float m = kNegB;
 #pragma unroll
@@ -251,7 +280,7 @@ __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankPar
         float ssum = 0.f, blank_part = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            v[k] = s0 + k < n ? fast_exp(v[k] - m) : 0.f;
+            v[k] = s0 + k < n ? __builtin_amdgcn_exp2f(v[k] - m) : 0.f;     // lattice is in log2 units
             ssum += v[k];
             if (((s0 + k) & 1) == 0) blank_part += v[k];
         }
@@ -271,9 +300,24 @@ __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankPar
                 occ[cls[s]] = tot;
             }
         }
-        const float *row = p.lp + (int64_t)t * p.st + (int64_t)b * p.sb;
         const float gs = p.grad_scale / (float)(L > 1 ? L : 1);
-        for (int c = lane; c < p.C; c += kWave) g[c] = (fast_exp(row[c]) - occ[c]) * gs;
+        if (VEC4) {
+#pragma unroll
+            for (int i = 0; i < kMaxV4; ++i) {
+                const int q = lane + kWave * i;
+                if (q < (p.C >> 2)) {
+                    const float4 o = reinterpret_cast<const float4 *>(occ)[q];
+                    float4 r;
+                    r.x = (fast_exp(xr[i].x) - o.x) * gs;
+                    r.y = (fast_exp(xr[i].y) - o.y) * gs;
+                    r.z = (fast_exp(xr[i].z) - o.z) * gs;
+                    r.w = (fast_exp(xr[i].w) - o.w) * gs;
+                    reinterpret_cast<float4 *>(g)[q] = r;
+                }
+            }
+        } else {
+            for (int c = lane; c < p.C; c += kWave) g[c] = (fast_exp(row[c]) - occ[c]) * gs;
+        }
         // un-set only what this row touched
         if (lane == 0) occ[p.blank] = 0.f;
 #pragma unroll
@@ -305,8 +349,11 @@ static int run_blank(BlankParams &p, hipStream_t s)
     const int total = p.T * p.B;
     int blocks = (total + kGradWaves - 1) / kGradWaves;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    return launch<blank_grad_kernel<K>>(dim3(blocks), dim3(kGradWaves * kWave),
-                                        (size_t)kGradWaves * (p.C + p.NSP) * sizeof(float), s, p, total);
+    const size_t lds = (size_t)kGradWaves * (((p.C + 3) & ~3) + p.NSP) * sizeof(float);
+    const bool vec4 = (p.C % 4 == 0) && p.C <= 4 * kWave * kMaxV4 && (p.st % 4 == 0) && (p.sb % 4 == 0) &&
+                      (reinterpret_cast<uintptr_t>(p.lp) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.grad) % 16 == 0);
+    if (vec4) return launch<blank_grad_kernel<K, true>>(dim3(blocks), dim3(kGradWaves * kWave), lds, s, p, total);
+    return launch<blank_grad_kernel<K, false>>(dim3(blocks), dim3(kGradWaves * kWave), lds, s, p, total);
 }
 
 }  // namespace ctc
@@ -325,7 +372,7 @@ extern "C" int ctc_amd_blank_loss_grad(const float *log_probs, int64_t stride_t,
     if (T < 1 || B < 1 || C < 1 || S < 1 || blank < 0 || blank >= C) return CTC_AMD_ERR_BAD_ARGUMENT;
     const int ns = 2 * S + 1;
     if (ns > kWave * 8) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;                 // S <= 255
-    if ((size_t)kGradWaves * (C + kWave * 8) * sizeof(float) > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    if ((size_t)kGradWaves * (C + 4 + kWave * 8) * sizeof(float) > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
     BlankParams p;
     p.lp = log_probs; p.st = stride_t; p.sb = stride_b;
     p.tgt = targets; p.tgt64 = targets_i64;
