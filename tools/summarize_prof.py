@@ -57,8 +57,11 @@ def main():
                          "(requests x 64 B = %.0f B = FETCH_SIZE)" % (n32, n64, n128, rd, 64 * (n32 + n64 + n128)))
         lines.append("* **traffic = reads %.0f B + writes %.0f B = %.0f B per launch** (logits once = %.0f B)"
                      % (rd, ws, rd + ws, x_bytes))
-        out.update({"hbm_bytes_per_launch": round(rd + ws), "read_bytes": round(rd), "write_bytes": round(ws),
-                    "fetch_size_raw_bytes": round(fs), "kernel": k[:120]})
+        out["hbm_bytes_per_launch"] = out.get("hbm_bytes_per_launch", 0) + round(rd + ws)   # summed over the
+        out["read_bytes"] = out.get("read_bytes", 0) + round(rd)                              # variant's kernels
+        out["write_bytes"] = out.get("write_bytes", 0) + round(ws)
+        out["fetch_size_raw_bytes"] = out.get("fetch_size_raw_bytes", 0) + round(fs)
+        out.setdefault("kernels", []).append(k[:120])
         lines.append("")
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     open(dst + ".md", "w").write("\n".join(lines) + "\n")
