@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
     const float mask_tail = lane + 64 * (CH - 1) < p.C ? 0.f : ninf;   // only the last chunk is partial
     const int lab_l = lane < p.SP ? sm.lab[lane] : 0;
     const int lab_src = lab_l & 63, lab_chunk = lab_l >> 6;
-    float mlrow[kPipeRows];                                  // (max + log-sum) * log2(e) per slot
+    float rsrow[kPipeRows];                                  // grad_scale / sum_c exp(x - max) per slot
 #pragma unroll
     for (int gq = 0; gq < kPipeRows / kGroup; ++gq) {        // P1: extremes first
         float m[kGroup], sum[kGroup];
@@ -242,12 +242,26 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
             for (int j = 0; j < CH - 1; ++j) m[k] = fmaxf(m[k], v[r][j]);
         }
         wave_max4(m[0], m[1], m[2], m[3]);
+        float xv[kGroup];
 #pragma unroll
         for (int k = 0; k < kGroup; ++k) {
             const int r = gq * kGroup + k;
-            sum[k] = __builtin_amdgcn_exp2f((v[r][CH - 1] + mask_tail - m[k]) * kLog2e);
+            xv[k] = 0.f;
 #pragma unroll
-            for (int j = 0; j < CH - 1; ++j) sum[k] += __builtin_amdgcn_exp2f((v[r][j] - m[k]) * kLog2e);
+            for (int j = 0; j < CH; ++j) {                   // gather x[t, lab_l] out of the row registers
+                const float q = __shfl(v[r][j], lab_src, kWave);
+                if (lab_chunk == j) xv[k] = q;
+            }
+            // the row registers now become exp(x - max): the gradient pass needs softmax(x) =
+            // that times 1/sum, so no second exp per element; the emission above used x itself
+            const float mb = -m[k] * kLog2e;
+            v[r][CH - 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[r][CH - 1] + mask_tail, kLog2e, mb));
+            sum[k] = v[r][CH - 1];
+#pragma unroll
+            for (int j = 0; j < CH - 1; ++j) {
+                v[r][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[r][j], kLog2e, mb));
+                sum[k] += v[r][j];
+            }
         }
         wave_sum4(sum[0], sum[1], sum[2], sum[3]);
 #pragma unroll
@@ -255,17 +269,11 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
             const int r = gq * kGroup + k;
             const int t = pipe_row(p.T, u, r);
             const float lsum = fast_log(sum[k]);
-            mlrow[r] = (m[k] + lsum) * kLog2e;
-            asm volatile("" : "+v"(mlrow[r]));               // keep it in a VGPR: 12 wave-uniform floats
+            rsrow[r] = p.grad_scale * __builtin_amdgcn_rcpf(sum[k]);   // grad_scale / sum_c exp(x - max)
+            asm volatile("" : "+v"(rsrow[r]));               // keep it in a VGPR: 12 wave-uniform floats
                                                              // would spill the scalar file
-            float xv = 0.f;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {                   // gather x[t, lab_l] out of the row registers
-                const float q = __shfl(v[r][j], lab_src, kWave);
-                if (lab_chunk == j) xv = q;
-            }
             if (t >= 0 && t < Tb && lane < p.SP)             // (t: wave-uniform)
-                sm.em[t * p.SP + lane] = (lane < L) ? (xv - m[k]) - lsum : kNeg;
+                sm.em[t * p.SP + lane] = (lane < L) ? (xv[k] - m[k]) - lsum : kNeg;
             if (lane == 0) sm.cnt[u] = r + 1;                // publishes the slot (same wave: in order)
         }
     }
@@ -308,6 +316,8 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
     const int lcl = lane < p.SP ? lane : 0;
     const bool in = lane < L;
     const float gsc = p.grad_scale;
+    float shift = 0.f;                                       // row shift of the posterior softmax
+    bool have_shift = false;
     typedef const volatile __attribute__((address_space(3))) int lds_cvint;
 
     // P3: middle-out, one look at the chains' progress per group of four slots
@@ -334,15 +344,23 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
         float z[kGroup], pe[kGroup];
 #pragma unroll
         for (int k = 0; k < kGroup; ++k) {
-            const int off = (tt[k] >= 0 && tt[k] < Tlive ? tt[k] : 0) * p.SP + lcl;
+            const bool lv = tt[k] >= 0 && tt[k] < Tlive;       // wave-uniform; idle slots read row 0 and
+            const int off = (lv ? tt[k] : 0) * p.SP + lcl;     // are masked (row 0 may not exist yet)
             const float zz = sm.al[off] + sm.be[off] - sm.em[off];
-            z[k] = in ? zz : ninf;
+            z[k] = (in && lv) ? zz : ninf;
             pe[k] = z[k];
         }
-        wave_max4(z[0], z[1], z[2], z[3]);
+        // Any shift gives the same softmax; every row's log-normaliser equals -nll up to the
+        // rounding of the two scans, so the maximum found for the first (middle) group serves all
+        // later rows too: z - shift stays <= ~0, and the row sum still normalises exactly.
+        if (!have_shift && need_a > 0) {                     // first group with a live row (wave-uniform)
+            wave_max4(z[0], z[1], z[2], z[3]);
+            shift = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));     // idle slots contribute -inf
+            have_shift = true;
+        }
 #pragma unroll
         for (int k = 0; k < kGroup; ++k) {
-            pe[k] = __builtin_amdgcn_exp2f((pe[k] - z[k]) * kLog2e);     // exp2(-inf) = 0 beyond L
+            pe[k] = __builtin_amdgcn_exp2f((pe[k] - shift) * kLog2e);    // exp2(-inf) = 0 beyond L
             z[k] = pe[k];
         }
         wave_sum4(z[0], z[1], z[2], z[3]);
@@ -351,22 +369,28 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
             const int r = gq * kGroup + k, t = tt[k];
             if (t < 0) continue;                             // wave-uniform
             float *g = p.grad + ((int64_t)t * p.B + b) * p.C;
-            const bool live = t < Tlive;                     // wave-uniform; dead rows get zeros
-            const int off = (live ? t : 0) * p.SP;
-            if (live && lane < p.SP) sm.be[off + lane] = pe[k] * __builtin_amdgcn_rcpf(z[k]);
-            if (any_dup && live && my_dup) {                 // fold repeats onto the first occurrence
+            if (t >= Tlive) {                                // wave-uniform: dead row
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int c = lane + 64 * j;
+                    if (j < CH - 1 || c < p.C) g[c] = 0.f;
+                }
+                continue;
+            }
+            const int off = t * p.SP;
+            // gamma * grad_scale goes to LDS, so the dense row is one fma and one subtract
+            if (lane < p.SP) sm.be[off + lane] = pe[k] * (gsc * __builtin_amdgcn_rcpf(z[k]));
+            if (any_dup && my_dup) {                         // fold repeats onto the first occurrence
                 float tot = sm.be[off + lane];
                 for (int n = sm.nxt[lane]; n >= 0; n = sm.nxt[n]) tot += sm.be[off + n];
                 sm.be[off + lane] = tot;
             }
-            const float gl = live ? gsc : 0.f;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const int c = lane + 64 * j;
                 const float occ = sm.be[off + first[j]];
-                const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(v[r][j], kLog2e, -mlrow[r]));
-                const float gv = gl * (pr - (has[j] ? occ : 0.f));
-                if (j < CH - 1 || c < p.C) g[c] = live ? gv : 0.f;
+                const float gv = __builtin_fmaf(v[r][j], rsrow[r], has[j] ? -occ : 0.f);
+                if (j < CH - 1 || c < p.C) g[c] = gv;
             }
         }
     }
