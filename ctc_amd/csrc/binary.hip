@@ -63,6 +63,19 @@ __device__ __forceinline__ void bce_logs(float x, float &p, float &lp, float &lq
     lq = fmaxf(logf(1.0f - p), -100.0f);
 }
 
+// same, with the raw v_log_f32 for the two logs: p itself still comes from the accurate expf
+// (where 1-p cancels, the reference's value depends on the last bit of p), while a log only has
+// to be good to ~1e-7 relative, which the hardware op is
+__device__ __forceinline__ void bce_logs_fast(float x, float &p, float &lp, float &lq)
+{
+    p = __builtin_amdgcn_rcpf(1.0f + expf(-x));
+    const float one_m_p = 1.0f - p;
+    // v_log_f32 does not handle denormals: p >= 2^-126 unless x < -87 (then log p <= -87 anyway
+    // and the clamp below is what matters only beyond -100: use the accurate path there)
+    lp = x < -80.0f ? fmaxf(logf(p), -100.0f) : __builtin_amdgcn_logf(p) * kLn2;
+    lq = one_m_p > 0.0f ? fmaxf(__builtin_amdgcn_logf(one_m_p) * kLn2, -100.0f) : -100.0f;
+}
+
 template <int K>
 __global__ __launch_bounds__(kBinThreads) void binary_fused_kernel(BinaryParams p)
 {
@@ -246,7 +259,8 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
         for (int j = 0; j < CH; ++j) {
             const int c = lane + 64 * j;
             float pr, lp, lq;
-            bce_logs(v[r][j], pr, lp, lq);
+            bce_logs_fast(v[r][j], pr, lp, lq);
+            v[r][j] = pr;                                    // the gradient needs sigmoid(x), not x
             const bool in = c < p.C && t < Tb;
             if (c < PD) sm.dimg[t * PD + c] = in ? lp - lq : 0.f;    // zero K padding / dead rows
             q += in ? lq : 0.f;
@@ -332,10 +346,10 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
         for (int j = 0; j < CH; ++j) {
             const int c = lane + 64 * j;
             if (c < p.C) {
-                const float pr = 1.0f / (1.0f + expf(-v[r][j]));
+                const float pr = v[r][j];                    // sigmoid(x), kept from P1a
                 const float pq = pr * (1.0f - pr);
                 const float occ = sm.dimg[t * PD + c];
-                g[c] = live ? gs * (pr - occ) * (pq / fmaxf(pq, 1e-12f)) : 0.f;
+                g[c] = live ? gs * (pr - occ) * (pq * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f))) : 0.f;
             }
         }
     }
