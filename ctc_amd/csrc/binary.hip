@@ -311,7 +311,14 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
     // P3a: posteriors (rows round-robin over the waves)
     const bool feasible = ok && nll < kInfeasible;
     const int Tlive = feasible ? Tb : 0;
-    {
+    if (K == 1) {                                            // S <= 64: four rows per pass, interleaved reductions
+        for (int t0 = w * 4; t0 < Tlive; t0 += kBinWaves * 4) {
+            int tt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tt[k] = t0 + k < Tlive ? t0 + k : -1;
+            posterior_rows4(sm.al, sm.be, sm.em, tt, L, p.SP, 1.0f);
+        }
+    } else {
         const int G = posterior_group(p.SP), per = kWave / G, sub = lane / G;
         for (int t0 = w * per; t0 < Tlive; t0 += kBinWaves * per)
             posterior_row<false>(sm.al, sm.be, sm.em, nullptr, nullptr, t0 + sub, t0 + sub < Tlive, L, p.SP, G);

@@ -140,6 +140,34 @@ __device__ __forceinline__ void posterior_row(const float *al, float *be, const 
             }
 }
 
+// Four posterior rows at once for S <= 64 (one label per lane): the two reductions of each
+// row are interleaved four-wide (wave_max4 / wave_sum4, common.hpp), gamma * `scale` is
+// written over `be`.  t[k] < 0 marks an idle slot.  No repeat folding (binary variant).
+__device__ __forceinline__ void posterior_rows4(const float *al, float *be, const float *em, const int (&t)[4],
+                                                int L, int SP, float scale)
+{
+    const int lane = lane_id(), lcl = lane < SP ? lane : 0;
+    const float ninf = -__builtin_inff();
+    float z[4], pe[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int off = (t[k] >= 0 ? t[k] : 0) * SP + lcl;
+        const float zz = al[off] + be[off] - em[off];
+        z[k] = (lane < L && t[k] >= 0) ? zz : ninf;
+        pe[k] = z[k];
+    }
+    wave_max4(z[0], z[1], z[2], z[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pe[k] = __builtin_amdgcn_exp2f((pe[k] - (t[k] >= 0 ? z[k] : 0.f)) * kLog2e);
+        z[k] = pe[k];
+    }
+    wave_sum4(z[0], z[1], z[2], z[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (t[k] >= 0 && lane < SP) be[t[k] * SP + lane] = pe[k] * (scale * __builtin_amdgcn_rcpf(z[k]));
+}
+
 __device__ __forceinline__ int posterior_group(int SP) { return SP <= 16 ? 16 : (SP <= 32 ? 32 : 64); }
 
 }  // namespace ctc
