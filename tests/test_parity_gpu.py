@@ -34,7 +34,7 @@ def run_hip(fn, x, tg, il, tl, dev, lens_on_gpu=True, **kw):
     loss, nll = fn(xd, tgd, ild, tld, **kw)
     loss.backward()
     torch.cuda.synchronize()
-    return {"loss": float(loss), "nll": np_(nll), "grad": np_(xd.grad)}
+    return {"loss": float(loss.detach()), "nll": np_(nll), "grad": np_(xd.grad)}
 
 
 def assert_close(r, ref, grad_atol, nll_rtol=NLL_RTOL):
@@ -279,3 +279,53 @@ def test_noblank_best_path(dev, shape):
     got = ctc_numpy.path_score(np_(x), np_(lab), path, np_(Tb))
     assert np.abs(got - rs).max() <= 1e-4
     assert (path == rp).mean() > 0.98
+
+
+# ------------------------------------------------------------------ kernel-path boundaries
+@pytest.mark.parametrize("shape", [
+    (1, 1, 1, 1),        # smallest possible
+    (1, 3, 5, 1),        # T = 1
+    (165, 3, 70, 9),     # pipelined kernel beyond 160 rows (<= 168)
+    (168, 2, 33, 10),    # pipelined kernel, last supported T
+    (169, 2, 33, 10),    # phase-serial kernel, two row passes
+    (400, 2, 40, 12),    # phase-serial kernel, three row passes
+    (30, 9, 256, 64),    # S = 64 (no idle lane: shr/shl chain form), C = 256
+    (30, 2, 257, 65),    # S = 65 -> 2 states per lane, C > 256 -> strided rows
+    (12, 2, 20, 256),    # S = 256 -> 4 states per lane (L_b <= T_b limits the live states)
+])
+def test_noblank_kernel_path_boundaries(dev, shape):
+    import ctc_amd
+    T, B, C, S = shape
+    x, lab, Tb, L = synth_noblank(17 + sum(shape), T, B, C, S, var_T=T > 4)
+    L = torch.minimum(L, Tb)
+    ref = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+    assert_close(r, ref, 2e-6 * max(1.0, 256.0 / B))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (170, 2, 40, 12), (160, 2, 158, 20), (30, 2, 257, 6),
+                                   (30, 3, 64, 64), (20, 2, 30, 70)])
+def test_binary_kernel_path_boundaries(dev, shape):
+    import ctc_amd
+    T, B, C, S = shape
+    x, y, Tb, L = synth_binary(23 + sum(shape), T, B, C, S, var_T=T > 4, density=0.2)
+    L = torch.minimum(L, Tb)
+    ref = ctc_c.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float64)
+    r = run_hip(ctc_amd.binary_ctc_loss, x, y, Tb, L, dev)
+    assert_close(r, ref, 2e-7 * max(1.0, 256.0 / B))
+
+
+def test_unsupported_shapes_raise(dev):
+    import ctc_amd
+    # the T x S lattice of the no-blank kernels lives in LDS (160 KB): beyond it the C ABI
+    # reports "unsupported shape" and the Python layer raises -- never a silent fallback
+    x, lab, Tb, L = synth_noblank(1, 3000, 1, 8, 20)
+    with pytest.raises(ctc_amd.CtcAmdError):
+        ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), Tb, L)
+    x, lab, Tb, L = synth_noblank(1, 4, 1, 8, 300)
+    with pytest.raises(ctc_amd.CtcAmdError):
+        ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), Tb, torch.minimum(L, Tb))
+    with pytest.raises(ValueError):
+        ctc_amd.noblank_ctc_loss(x.to(dev).double(), lab.to(dev), Tb, L)
+    with pytest.raises(ValueError):
+        ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), torch.tensor([9]), L)     # T_b > T (CPU lengths: checked)
