@@ -166,10 +166,10 @@ __global__ __launch_bounds__(kBinThreads) void binary_fused_kernel(BinaryParams 
                     float occ = 0.f;
                     for (int l = 0; l < L; ++l) occ = __builtin_fmaf(gam[l], sm.ys[l * p.CP + c], occ);
                     const float pq = pr * (1.0f - pr);
-                    g[c] = gs * (pr * tot - occ) * (pq / fmaxf(pq, 1e-12f));
+                    stream_store(&g[c], gs * (pr * tot - occ) * (pq / fmaxf(pq, 1e-12f)));
                 }
             } else {
-                for (int c = lane; c < p.C; c += kWave) g[c] = 0.f;
+                for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], 0.f);
             }
         }
     }
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
                 const float pr = v[r][j];                    // sigmoid(x), kept from P1a
                 const float pq = pr * (1.0f - pr);
                 const float occ = sm.dimg[t * PD + c];
-                g[c] = live ? gs * (pr - occ) * (pq * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f))) : 0.f;
+                stream_store(&g[c], live ? gs * (pr - occ) * (pq * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f))) : 0.f);
             }
         }
     }

@@ -250,9 +250,9 @@ __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankPar
         const float nllb = p.nll[b];
         if (!ok || t >= Tb || !(nllb < 3.0e38f)) {           // beyond T_b, or no alignment: zero row
             if (VEC4) {
-                for (int q = lane; q < (p.C >> 2); q += kWave) reinterpret_cast<float4 *>(g)[q] = make_float4(0, 0, 0, 0);
+                for (int q = lane; q < (p.C >> 2); q += kWave) stream_store(reinterpret_cast<float4 *>(g) + q, make_float4(0, 0, 0, 0));
             } else {
-                for (int c = lane; c < p.C; c += kWave) g[c] = 0.f;
+                for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], 0.f);
             }
             continue;
         }
@@ -312,11 +312,11 @@ __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankPar
                     r.y = (fast_exp(xr[i].y) - o.y) * gs;
                     r.z = (fast_exp(xr[i].z) - o.z) * gs;
                     r.w = (fast_exp(xr[i].w) - o.w) * gs;
-                    reinterpret_cast<float4 *>(g)[q] = r;
+                    stream_store(reinterpret_cast<float4 *>(g) + q, r);
                 }
             }
         } else {
-            for (int c = lane; c < p.C; c += kWave) g[c] = (fast_exp(row[c]) - occ[c]) * gs;
+            for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], (fast_exp(row[c]) - occ[c]) * gs);
         }
         // un-set only what this row touched
         if (lane == 0) occ[p.blank] = 0.f;

@@ -151,14 +151,14 @@ struct Rows {
                     const int c = lane + 64 * j;
                     if (c < p.C) {
                         const float occ = first[j] >= 0 ? sm.be[t * p.SP + first[j]] : 0.f;
-                        g[c] = p.grad_scale * (fast_exp((v[r][j] - m) - lsum) - occ);
+                        stream_store(&g[c], p.grad_scale * (fast_exp((v[r][j] - m) - lsum) - occ));
                     }
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const int c = lane + 64 * j;
-                    if (c < p.C) g[c] = 0.f;
+                    if (c < p.C) stream_store(&g[c], 0.f);
                 }
             }
         }
@@ -198,10 +198,10 @@ __device__ __forceinline__ void rows_grad_generic(const NoblankParams &p, const 
             const float m = sm.mx[t], lsum = sm.ls[t];
             for (int c = lane; c < p.C; c += kWave) {
                 const int f = sm.inv[c];
-                g[c] = p.grad_scale * (fast_exp((row[c] - m) - lsum) - (f >= 0 ? sm.be[t * p.SP + f] : 0.f));
+                stream_store(&g[c], p.grad_scale * (fast_exp((row[c] - m) - lsum) - (f >= 0 ? sm.be[t * p.SP + f] : 0.f)));
             }
         } else {
-            for (int c = lane; c < p.C; c += kWave) g[c] = 0.f;
+            for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], 0.f);
         }
     }
 }

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const int c = lane + 64 * j;
-                    if (j < CH - 1 || c < p.C) g[c] = 0.f;
+                    if (j < CH - 1 || c < p.C) stream_store(&g[c], 0.f);
                 }
                 continue;
             }
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
                 const int c = lane + 64 * j;
                 const float occ = sm.be[off + first[j]];
                 const float gv = __builtin_fmaf(v[r][j], rsrow[r], has[j] ? -occ : 0.f);
-                if (j < CH - 1 || c < p.C) g[c] = gv;
+                if (j < CH - 1 || c < p.C) stream_store(&g[c], gv);
             }
         }
     }
