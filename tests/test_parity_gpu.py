@@ -329,3 +329,49 @@ def test_unsupported_shapes_raise(dev):
         ctc_amd.noblank_ctc_loss(x.to(dev).double(), lab.to(dev), Tb, L)
     with pytest.raises(ValueError):
         ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), torch.tensor([9]), L)     # T_b > T (CPU lengths: checked)
+
+
+def test_noblank_more_samples_than_cus(dev):
+    """B > #CUs selects the 64-VGPR build (two workgroups per CU); B % 8 != 0 exercises the
+    XCD-aware sample mapping's remainder handling."""
+    import ctc_amd
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    B = ncu + 37
+    x, lab, Tb, L = synth_noblank(77, 60, B, 70, 12, var_T=True)
+    ref = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64, threads=8)
+    r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+    assert_close(r, ref, 2e-6)
+    xb, y, Tb, L = synth_binary(78, 40, B, 40, 9, var_T=True, density=0.2)
+    ref = ctc_c.binary_ctc(np_(xb), np_(y), np_(Tb), np_(L), np.float64, threads=8)
+    r = run_hip(ctc_amd.binary_ctc_loss, xb, y, Tb, L, dev)
+    assert_close(r, ref, 2e-7)
+
+
+def test_autograd_path_is_graph_capturable(dev):
+    """the C ABI only enqueues work (no allocation, no host sync): forward + backward can be
+    captured into a hipGraph and replayed on new data in the same buffers"""
+    import ctc_amd
+    x, lab, Tb, L = synth_noblank(5, 30, 8, 20, 6, var_T=True)
+    xs = x.to(dev).requires_grad_(True)
+    labd, Tbd, Ld = lab.to(dev), Tb.to(dev), L.to(dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                     # warm-up on the capture stream (workspace, grads)
+        for _ in range(2):
+            xs.grad = None
+            loss = ctc_amd.CTCLoss.apply(xs, labd, Tbd, Ld)
+            loss.backward()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    xs.grad = None
+    with torch.cuda.graph(g):
+        loss = ctc_amd.CTCLoss.apply(xs, labd, Tbd, Ld)
+        loss.backward()
+    x2, _, _, _ = synth_noblank(6, 30, 8, 20, 6)
+    with torch.no_grad():
+        xs.copy_(x2.to(dev))
+    g.replay()
+    torch.cuda.synchronize()
+    ref = ctc_numpy.noblank_ctc(np_(x2), np_(lab), np_(Tb), np_(L), np.float64)
+    assert abs(float(loss.detach()) - float(ref["loss"])) < 1e-4 * max(1.0, abs(float(ref["loss"])))
+    assert np.abs(np_(xs.grad) - ref["grad"]).max() < 2e-6 * 32
