@@ -5,8 +5,8 @@ Drop-in for the loss path of gotaku6629/CTC: ``CTCLoss.apply`` plus ``NoBlankCTC
 """
 from ._lib import CtcAmdError, SO_PATH  # noqa: F401
 from .functional import (CTCLoss, binary_ctc_loss, blank_ctc_loss,  # noqa: F401
-                         noblank_best_path, noblank_ctc_loss)
+                         noblank_best_path, noblank_ctc_loss, noblank_posteriors)
 from .modules import BlankCTC, NoBlankBinaryCTC, NoBlankCTC  # noqa: F401
 
 __all__ = ["CTCLoss", "NoBlankCTC", "NoBlankBinaryCTC", "BlankCTC", "noblank_ctc_loss",
-           "binary_ctc_loss", "blank_ctc_loss", "noblank_best_path", "CtcAmdError"]
+           "binary_ctc_loss", "blank_ctc_loss", "noblank_best_path", "noblank_posteriors", "CtcAmdError"]

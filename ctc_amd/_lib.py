@@ -26,6 +26,8 @@ PROTOTYPES = {
     "ctc_amd_scale_grad": (_int, [_vp, _vp, _sz, _vp]),
     "ctc_amd_noblank_best_path": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _int,
                                          _vp, _vp, _vp, _vp]),
+    "ctc_amd_noblank_posteriors": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _int,
+                                          _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

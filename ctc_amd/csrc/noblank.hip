@@ -39,6 +39,7 @@ struct NoblankParams {
                                 // pairs into workspace bytes [64,256) at each phase boundary
     float loss_scale, grad_scale;
     float *nll, *loss, *grad;
+    float *gamma;               // optional [B][T][S] posteriors output (ctc_amd_noblank_posteriors)
     unsigned *counter;
 };
 
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
         if (w == 0) {
             if (rot) lattice_chain<K, true, true>(sm.em, sm.al, sm.dummy, Tb, L, p.SP);
             else lattice_chain<K, true, false>(sm.em, sm.al, sm.dummy, Tb, L, p.SP);
-        } else if (w == 1 && p.grad) {
+        } else if (w == 1 && (p.grad || p.gamma)) {
             if (rot) lattice_chain<K, false, true>(sm.em, sm.be, sm.dummy, Tb, L, p.SP);
             else lattice_chain<K, false, false>(sm.em, sm.be, sm.dummy, Tb, L, p.SP);
         }
@@ -316,11 +317,22 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
     if (w == kWaves - 1)
         publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
                            [](float v, int) { return v; });
-    if (!p.grad) return;
+    if (!p.grad && !p.gamma) return;
 
     // P3
     const bool feasible = ok && nll < kInfeasible;
     const int Tlive = feasible ? Tb : 0;
+    if (p.gamma) {                                           // posteriors output (no folding): own pass
+        const int G = posterior_group(p.SP), per = kWave / G, sub = lane_id() / G;
+        for (int t0 = w * per; t0 < p.T; t0 += kWaves * per) {
+            const int t = t0 + sub;
+            posterior_row<false>(sm.al, sm.be, sm.em, nullptr, nullptr, t, t < Tlive, L, p.SP, G);
+            if (t < p.T)
+                for (int l = lane_id() % G; l < p.S; l += G)
+                    p.gamma[((int64_t)b * p.T + t) * p.S + l] = t < Tlive ? sm.be[t * p.SP + l] : 0.f;
+        }
+        return;
+    }
     if (CH > 0) {
         const int lane = lane_id();
         int first[CHR];
@@ -417,7 +429,7 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     static const int debug_stop = getenv("CTC_AMD_DEBUG_STOP") ? atoi(getenv("CTC_AMD_DEBUG_STOP")) : 0;
     p.stop = debug_stop;
     p.loss_scale = loss_scale; p.grad_scale = grad_scale;
-    p.nll = nll; p.loss = loss; p.grad = grad;
+    p.nll = nll; p.loss = loss; p.grad = grad; p.gamma = nullptr;
     p.counter = static_cast<unsigned *>(workspace);
     const size_t smem = noblank_smem_bytes(T, p.SP, C);
     if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
@@ -467,4 +479,39 @@ extern "C" int ctc_amd_scale_grad(float *grad, const float *grad_out, size_t n, 
     hipLaunchKernelGGL(scale_grad_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), grad, grad_out, n);
     return (int)hipGetLastError();
+}
+
+extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int64_t stride_b,
+                                          const void *labels, int labels_i64,
+                                          const int64_t *in_len, const int64_t *tgt_len,
+                                          int T, int B, int C, int S,
+                                          float *nll, float *gamma,
+                                          void *workspace, void *stream)
+{
+    if (!x || !labels || !in_len || !tgt_len || !nll || !gamma || !workspace) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (T < 1 || B < 1 || C < 1 || S < 1) return CTC_AMD_ERR_BAD_ARGUMENT;
+    int K = 1;
+    while (K <= 4 && S > kWave * K) K *= 2;
+    if (K > 4) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    NoblankParams p;
+    p.x = x; p.st = stride_t; p.sb = stride_b;
+    p.lab = labels; p.lab64 = labels_i64;
+    p.in_len = in_len; p.tgt_len = tgt_len;
+    p.T = T; p.B = B; p.C = C; p.S = S;
+    p.SP = (S + K - 1) / K * K;
+    p.stop = 0;
+    p.loss_scale = 0.f; p.grad_scale = 0.f;
+    p.nll = nll; p.grad = nullptr; p.gamma = gamma;
+    // the batch-mean slot of the in-launch reduction lands in a spare workspace word
+    p.counter = static_cast<unsigned *>(workspace);
+    p.loss = reinterpret_cast<float *>(static_cast<char *>(workspace) + 32);
+    const size_t smem = noblank_smem_bytes(T, p.SP, C);
+    if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int ch = C <= 256 ? (C + kWave - 1) / kWave : 0;    // phase-serial kernel: any supported shape
+    switch (K) {
+        case 1: return launch_noblank<1>(ch, smem, s, p);
+        case 2: return launch_noblank<2>(ch, smem, s, p);
+        default: return launch_noblank<4>(ch, smem, s, p);
+    }
 }

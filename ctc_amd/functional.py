@@ -250,3 +250,37 @@ def noblank_best_path(logits, targets, input_lengths, target_lengths):
             _stream_handle(dev))
     _lib.check(rc, "ctc_amd_noblank_best_path")
     return path, score
+
+
+def noblank_posteriors(logits, targets, input_lengths, target_lengths):
+    """Per-step state posteriors of the no-blank lattice -> (gamma[B,T,S], nll[B]).
+
+    ``gamma[b,t,l]`` = P(label position l at step t | logits, targets): the soft alignment whose
+    class-scatter is the loss gradient; rows sum to 1 for ``t < T_b``.  SURVEY 8(f) rank 1.
+    """
+    _require_hip(logits, "logits")
+    if logits.dim() != 3 or logits.dtype != torch.float32:
+        raise ValueError("ctc_amd: logits must be float32 [T,B,C]")
+    T, B, C = logits.shape
+    dev = logits.device
+    xs = logits.detach()
+    if xs.stride(2) != 1:
+        xs = xs.contiguous()
+    if _variant_of(targets) != _lib.NOBLANK or targets.shape[0] != B:
+        raise ValueError("ctc_amd: targets must be [B,S] integer")
+    if targets.dtype not in (torch.int32, torch.int64):
+        targets = targets.long()
+    tg = targets.to(device=dev, non_blocking=True).contiguous()
+    S = tg.shape[1]
+    il = _lengths(input_lengths, B, "input_lengths", dev, T)
+    tl = _lengths(target_lengths, B, "target_lengths", dev, S)
+    gamma = torch.empty((B, T, S), dtype=torch.float32, device=dev)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _workspace(_lib.NOBLANK, T, B, C, S, dev)
+        rc = _lib.load().ctc_amd_noblank_posteriors(
+            xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(), int(tg.dtype == torch.int64),
+            il.data_ptr(), tl.data_ptr(), T, B, C, S, nll.data_ptr(), gamma.data_ptr(), ws.data_ptr(),
+            _stream_handle(dev))
+    _lib.check(rc, "ctc_amd_noblank_posteriors")
+    return gamma, nll

@@ -115,6 +115,17 @@ int ctc_amd_noblank_best_path(const float *x, int64_t stride_t, int64_t stride_b
                               int32_t *path, float *score,
                               void *workspace, void *stream);
 
+/* Per-step posteriors of the no-blank lattice: gamma[b,t,l] = P(state l at step
+ * t | x, targets) = exp(alpha_t(l) + beta_t(l) + nll), the quantity the loss gradient scatters
+ * by class; rows sum to 1 for t < T_b and are 0 beyond T_b / L_b.  Same inputs as
+ * ctc_amd_noblank_loss_grad; gamma is [B,T,S] fp32 contiguous; nll [B] is also produced. */
+int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int64_t stride_b,
+                               const void *labels, int labels_i64,
+                               const int64_t *in_len, const int64_t *tgt_len,
+                               int T, int B, int C, int S,
+                               float *nll, float *gamma,
+                               void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -375,3 +375,20 @@ def test_autograd_path_is_graph_capturable(dev):
     ref = ctc_numpy.noblank_ctc(np_(x2), np_(lab), np_(Tb), np_(L), np.float64)
     assert abs(float(loss.detach()) - float(ref["loss"])) < 1e-4 * max(1.0, abs(float(ref["loss"])))
     assert np.abs(np_(xs.grad) - ref["grad"]).max() < 2e-6 * 32
+
+
+@pytest.mark.parametrize("shape", [(20, 4, 10, 5), (150, 8, 158, 20), (40, 3, 300, 70)])
+def test_noblank_posteriors(dev, shape):
+    import ctc_amd
+    T, B, C, S = shape
+    x, lab, Tb, L = synth_noblank(sum(shape) + 3, T, B, C, S, var_T=True)
+    gamma, nll = ctc_amd.noblank_posteriors(x.to(dev), lab.to(dev), Tb.to(dev), L.to(dev))
+    torch.cuda.synchronize()
+    gamma, nll = np_(gamma), np_(nll)
+    ref = ctc_numpy.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    assert np.abs(gamma - ref["gamma"].transpose(1, 0, 2)).max() < 2e-4      # fp32 scans: ~1e-4 relative
+    assert (np.abs(nll - ref["nll"]) <= 1e-5 * np.abs(ref["nll"])).all()
+    for b in range(B):
+        assert np.abs(gamma[b, :int(Tb[b])].sum(axis=1) - 1.0).max() < 1e-5     # a distribution per live step
+        assert np.abs(gamma[b, int(Tb[b]):]).max(initial=0.0) == 0.0
+        assert np.abs(gamma[b, :, int(L[b]):]).max(initial=0.0) == 0.0
