@@ -129,6 +129,37 @@ __device__ __forceinline__ void wave_sum4(float &a, float &b, float &c, float &d
     a = lane63(a); b = lane63(b); c = lane63(c); d = lane63(d);
 }
 
+// Two independent reductions over the two 32-lane HALVES of the wave (two rows of <= 32 states
+// side by side): five DPP steps, two chains interleaved plus one s_nop per step for the
+// VALU->DPP hazard.  Half totals end up in lanes 31 and 63; every lane gets its half's value.
+#define CTC_DPP2(OP, CTRL)                                     \
+    OP " %0, %0, %0 " CTRL " bank_mask:0xf\n\t"                \
+    OP " %1, %1, %1 " CTRL " bank_mask:0xf\n\t"                \
+    "s_nop 0\n\t"
+#define CTC_REDUCE2_HALVES(OP)                                 \
+    "s_nop 1\n\t"                                              \
+    CTC_DPP2(OP, "quad_perm:[1,0,3,2] row_mask:0xf")           \
+    CTC_DPP2(OP, "quad_perm:[2,3,0,1] row_mask:0xf")           \
+    CTC_DPP2(OP, "row_half_mirror row_mask:0xf")               \
+    CTC_DPP2(OP, "row_mirror row_mask:0xf")                    \
+    CTC_DPP2(OP, "row_bcast:15 row_mask:0xa")
+__device__ __forceinline__ float half_pick(float v, bool upper)
+{
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return upper ? hi : lo;
+}
+__device__ __forceinline__ void halves_sum2(float &a, float &b, bool upper)
+{
+    asm volatile(CTC_REDUCE2_HALVES("v_add_f32_dpp") : "+v"(a), "+v"(b));
+    a = half_pick(a, upper); b = half_pick(b, upper);
+}
+__device__ __forceinline__ void halves_max2(float &a, float &b, bool upper)
+{
+    asm volatile(CTC_REDUCE2_HALVES("v_max_f32_dpp") : "+v"(a), "+v"(b));
+    a = half_pick(a, upper); b = half_pick(b, upper);
+}
+
 // all-reduce inside aligned groups of G = 16 / 32 / 64 lanes, every lane gets the result
 template <bool MAX>
 __device__ __forceinline__ float group_reduce(float v, int G)

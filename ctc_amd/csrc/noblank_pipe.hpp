@@ -318,6 +318,10 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
     const float gsc = p.grad_scale;
     float shift = 0.f;                                       // row shift of the posterior softmax
     bool have_shift = false;
+    const bool pair = p.SP <= 32;                            // two posterior rows per wave pass
+    const bool upper = lane >= 32;
+    const int hl = lane & 31, hcl = hl < p.SP ? hl : 0;
+    const int my_dup_h = hl < p.SP ? sm.dup[hl] : 0;
     typedef const volatile __attribute__((address_space(3))) int lds_cvint;
 
     // P3: middle-out, one look at the chains' progress per group of four slots
@@ -340,30 +344,84 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
                 __builtin_amdgcn_s_sleep(8);
         }
         if (p.stop < 0) stamp(p, 3 + (2 - gq));             // diagnostic: groups 2,1,0 -> slots 3,4,5
-        // gamma_t = softmax_l(alpha_t + beta'_t - e_t): row-normalised posterior (lattice.hpp)
-        float z[kGroup], pe[kGroup];
-#pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            const bool lv = tt[k] >= 0 && tt[k] < Tlive;       // wave-uniform; idle slots read row 0 and
-            const int off = (lv ? tt[k] : 0) * p.SP + lcl;     // are masked (row 0 may not exist yet)
-            const float zz = sm.al[off] + sm.be[off] - sm.em[off];
-            z[k] = (in && lv) ? zz : ninf;
-            pe[k] = z[k];
-        }
+        // gamma_t = softmax_l(alpha_t + beta'_t - e_t): row-normalised posterior (lattice.hpp).
         // Any shift gives the same softmax; every row's log-normaliser equals -nll up to the
         // rounding of the two scans, so the maximum found for the first (middle) group serves all
         // later rows too: z - shift stays <= ~0, and the row sum still normalises exactly.
-        if (!have_shift && need_a > 0) {                     // first group with a live row (wave-uniform)
-            wave_max4(z[0], z[1], z[2], z[3]);
-            shift = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));     // idle slots contribute -inf
-            have_shift = true;
-        }
+        if (pair) {
+            // S <= 32: two rows side by side in the two 32-lane halves -> half the LDS reads,
+            // exps and reduction steps.  Slots (0,1) and (2,3) of the group form the two pairs.
+            float zp[2], pp[2];
+            int tl[2];
+            bool lvl[2];
 #pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            pe[k] = __builtin_amdgcn_exp2f((pe[k] - shift) * kLog2e);    // exp2(-inf) = 0 beyond L
-            z[k] = pe[k];
+            for (int q = 0; q < 2; ++q) {
+                tl[q] = upper ? tt[2 * q + 1] : tt[2 * q];
+                lvl[q] = tl[q] >= 0 && tl[q] < Tlive;        // per half
+                const int off = (lvl[q] ? tl[q] : 0) * p.SP + hcl;
+                const float zz = sm.al[off] + sm.be[off] - sm.em[off];
+                zp[q] = (hl < L && lvl[q]) ? zz : ninf;
+                pp[q] = zp[q];
+            }
+            if (!have_shift && need_a > 0) {
+                halves_max2(zp[0], zp[1], upper);
+                float mx = fmaxf(zp[0], zp[1]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));   // over both halves
+                shift = mx;
+                have_shift = true;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                pp[q] = __builtin_amdgcn_exp2f((pp[q] - shift) * kLog2e);    // exp2(-inf) = 0 beyond L
+                zp[q] = pp[q];
+            }
+            halves_sum2(zp[0], zp[1], upper);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int off = (lvl[q] ? tl[q] : 0) * p.SP;
+                // gamma * grad_scale goes to LDS, so the dense row is one fma and one subtract
+                if (lvl[q] && hl < p.SP) sm.be[off + hl] = pp[q] * (gsc * __builtin_amdgcn_rcpf(zp[q]));
+                if (any_dup && lvl[q] && my_dup_h) {         // fold repeats onto the first occurrence
+                    float tot = sm.be[off + hl];
+                    for (int n = sm.nxt[hl]; n >= 0; n = sm.nxt[n]) tot += sm.be[off + n];
+                    sm.be[off + hl] = tot;
+                }
+            }
+        } else {
+            float z[kGroup], pe[kGroup];
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) {
+                const bool lv = tt[k] >= 0 && tt[k] < Tlive;       // wave-uniform; idle slots read row 0 and
+                const int off = (lv ? tt[k] : 0) * p.SP + lcl;     // are masked (row 0 may not exist yet)
+                const float zz = sm.al[off] + sm.be[off] - sm.em[off];
+                z[k] = (in && lv) ? zz : ninf;
+                pe[k] = z[k];
+            }
+            if (!have_shift && need_a > 0) {                 // first group with a live row (wave-uniform)
+                wave_max4(z[0], z[1], z[2], z[3]);
+                shift = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));     // idle slots contribute -inf
+                have_shift = true;
+            }
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) {
+                pe[k] = __builtin_amdgcn_exp2f((pe[k] - shift) * kLog2e);    // exp2(-inf) = 0 beyond L
+                z[k] = pe[k];
+            }
+            wave_sum4(z[0], z[1], z[2], z[3]);
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) {
+                const int t = tt[k];
+                if (t < 0 || t >= Tlive) continue;           // wave-uniform
+                const int off = t * p.SP;
+                if (lane < p.SP) sm.be[off + lane] = pe[k] * (gsc * __builtin_amdgcn_rcpf(z[k]));
+                if (any_dup && my_dup) {
+                    float tot = sm.be[off + lane];
+                    for (int n = sm.nxt[lane]; n >= 0; n = sm.nxt[n]) tot += sm.be[off + n];
+                    sm.be[off + lane] = tot;
+                }
+            }
         }
-        wave_sum4(z[0], z[1], z[2], z[3]);
+        // dense rows: grad = softmax(x) * scale - gamma' gathered by class
 #pragma unroll
         for (int k = kGroup - 1; k >= 0; --k) {
             const int r = gq * kGroup + k, t = tt[k];
@@ -378,13 +436,6 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
                 continue;
             }
             const int off = t * p.SP;
-            // gamma * grad_scale goes to LDS, so the dense row is one fma and one subtract
-            if (lane < p.SP) sm.be[off + lane] = pe[k] * (gsc * __builtin_amdgcn_rcpf(z[k]));
-            if (any_dup && my_dup) {                         // fold repeats onto the first occurrence
-                float tot = sm.be[off + lane];
-                for (int n = sm.nxt[lane]; n >= 0; n = sm.nxt[n]) tot += sm.be[off + n];
-                sm.be[off + lane] = tot;
-            }
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const int c = lane + 64 * j;
