@@ -1,6 +1,8 @@
 // C-ABI entry points that are not tied to one kernel file (include/ctc_amd.h).
 #include "launch.hpp"
 
+namespace ctc { size_t noblank_extra_workspace(int T, int B, int C, int S); }   // noblank.hip
+
 extern "C" int ctc_amd_abi_version(void) { return CTC_AMD_ABI_VERSION; }
 
 extern "C" const char *ctc_amd_error_string(int code)
@@ -24,6 +26,6 @@ extern "C" size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int 
         const size_t nsp = ns <= 128 ? 128 : (ns <= 256 ? 256 : 512);
         bytes += 3 * (size_t)B * (size_t)T * nsp * sizeof(float) + 3 * (size_t)B * nsp * sizeof(int);
     }
-    (void)C;
+    if (variant == CTC_AMD_NOBLANK) bytes += ctc::noblank_extra_workspace(T, B, C, S);   // 0 while T x S fits in LDS
     return bytes;
 }

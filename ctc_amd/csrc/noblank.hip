@@ -40,6 +40,8 @@ struct NoblankParams {
     float loss_scale, grad_scale;
     float *nll, *loss, *grad;
     float *gamma;               // optional [B][T][S] posteriors output (ctc_amd_noblank_posteriors)
+    float *lattice;             // global-memory lattice slabs (workspace + 256 B) when T x S exceeds LDS
+    int64_t slab;               // floats per sample in `lattice`
     unsigned *counter;
 };
 
@@ -54,14 +56,17 @@ constexpr int kRowsPerPass = kWaves * kRows;
 struct NoblankSmem {
     float *em, *al, *be, *mx, *ls, *dummy;
     int *cnt, *lab, *nxt, *dup, *inv;
-    __device__ NoblankSmem(float *base, int T, int SP, int C)
+    // `glb` != nullptr: the T x S arrays live in that global slab (long sequences), only the
+    // small tables stay in LDS
+    __device__ NoblankSmem(float *base, int T, int SP, int C, float *glb = nullptr)
     {
-        em = base + kPrefetch * SP;                     // pad rows on both sides (lattice.hpp)
+        float *lat = glb ? glb : base;
+        em = lat + kPrefetch * SP;                      // pad rows on both sides (lattice.hpp)
         al = em + (size_t)(T + kPrefetch) * SP;
         be = al + (size_t)T * SP;
         mx = be + (size_t)T * SP;
         ls = mx + T;
-        dummy = ls + T;
+        dummy = glb ? base : ls + T;
         cnt = reinterpret_cast<int *>(dummy + 8);            // 16 progress counters (pipelined kernel)
         lab = cnt + 16;
         nxt = lab + SP;
@@ -70,9 +75,21 @@ struct NoblankSmem {
     }
 };
 
+static size_t noblank_lattice_floats(int T, int SP) { return (size_t)(3 * T + 2 * kPrefetch) * SP + 2 * (size_t)T; }
+static size_t noblank_tables_bytes(int SP, int C) { return (8 + 16 + 3 * (size_t)SP + C + 4) * 4; }
 static size_t noblank_smem_bytes(int T, int SP, int C)
 {
-    return ((size_t)(3 * T + 2 * kPrefetch) * SP + 2 * (size_t)T + 8 + 16 + 3 * (size_t)SP + C + 4) * 4;
+    return noblank_lattice_floats(T, SP) * 4 + noblank_tables_bytes(SP, C);
+}
+// extra workspace (beyond the first 256 B) of the no-blank entry points: 0 while the lattice
+// fits in LDS, else one slab per sample
+size_t noblank_extra_workspace(int T, int B, int C, int S)
+{
+    int K = 1;
+    while (K <= 4 && S > kWave * K) K *= 2;
+    const int SP = (S + K - 1) / K * K;
+    if (K > 4 || noblank_smem_bytes(T, SP, C) <= kMaxLds) return 0;
+    return (size_t)B * noblank_lattice_floats(T, SP) * 4;
 }
 
 __device__ __forceinline__ const float *row_ptr(const NoblankParams &p, int t, int b)
@@ -248,12 +265,15 @@ __device__ __forceinline__ void stamp(const NoblankParams &p, int slot)
     }
 }
 
-template <int K, int CH>   // CH = 0: generic rows (C > 256)
+// CH = 0: generic rows (C > 256).  GLB: lattice in global memory (T x S beyond LDS; slower:
+// the chains then prefetch their rows from L2) -- completeness path for long sequences.
+template <int K, int CH, bool GLB = false>
 __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p)
 {
     extern __shared__ float4 smem_raw[];
-    const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id();
+    const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C,
+                         GLB ? p.lattice + (int64_t)b * p.slab : nullptr);
     constexpr int CHR = CH > 0 ? CH : 1;
     Rows<CHR> rows;
 
@@ -394,6 +414,7 @@ template <int K>
 static int launch_noblank(int ch, size_t smem, hipStream_t s, const NoblankParams &p)
 {
     const dim3 grid(p.B), block(kThreads);
+    if (p.lattice) return launch<noblank_fused_kernel<K, 0, true>>(grid, block, smem, s, p);
     switch (ch) {
         case 1: return launch<noblank_fused_kernel<K, 1>>(grid, block, smem, s, p);
         case 2: return launch<noblank_fused_kernel<K, 2>>(grid, block, smem, s, p);
@@ -431,13 +452,19 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     p.loss_scale = loss_scale; p.grad_scale = grad_scale;
     p.nll = nll; p.loss = loss; p.grad = grad; p.gamma = nullptr;
     p.counter = static_cast<unsigned *>(workspace);
-    const size_t smem = noblank_smem_bytes(T, p.SP, C);
-    if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    p.lattice = nullptr; p.slab = 0;
+    size_t smem = noblank_smem_bytes(T, p.SP, C);
+    if (smem > kMaxLds) {                                    // long sequence: lattice in the workspace
+        smem = noblank_tables_bytes(p.SP, C);
+        if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+        p.lattice = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256);
+        p.slab = (int64_t)noblank_lattice_floats(T, p.SP);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int ch = C <= 256 ? (C + kWave - 1) / kWave : 0;
     // common case (S <= 64, C <= 256, T <= 168): the pipelined schedule
     static const bool no_pipe = getenv("CTC_AMD_NOPIPE") != nullptr;
-    if (K == 1 && ch >= 1 && T <= kPipeMaxT && !no_pipe) {
+    if (K == 1 && ch >= 1 && T <= kPipeMaxT && !no_pipe && !p.lattice) {
         const dim3 grid(B), block(kThreads);
         static const int cus = [] {
             int dev = 0, n = 256;
@@ -505,8 +532,14 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
     // the batch-mean slot of the in-launch reduction lands in a spare workspace word
     p.counter = static_cast<unsigned *>(workspace);
     p.loss = reinterpret_cast<float *>(static_cast<char *>(workspace) + 32);
-    const size_t smem = noblank_smem_bytes(T, p.SP, C);
-    if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    p.lattice = nullptr; p.slab = 0;
+    size_t smem = noblank_smem_bytes(T, p.SP, C);
+    if (smem > kMaxLds) {
+        smem = noblank_tables_bytes(p.SP, C);
+        if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+        p.lattice = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256);
+        p.slab = (int64_t)noblank_lattice_floats(T, p.SP);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int ch = C <= 256 ? (C + kWave - 1) / kWave : 0;    // phase-serial kernel: any supported shape
     switch (K) {

@@ -32,7 +32,7 @@ extern "C" {
 #define CTC_AMD_ABI_VERSION 1
 
 #define CTC_AMD_ERR_BAD_ARGUMENT      (-1)  /* null pointer, non-positive size ... */
-#define CTC_AMD_ERR_UNSUPPORTED_SHAPE (-2)  /* S or T*S beyond what the kernels tile */
+#define CTC_AMD_ERR_UNSUPPORTED_SHAPE (-2)  /* S > 256 (255 for blank-CTC); binary: T*S beyond LDS */
 
 /* variants for ctc_amd_workspace_bytes */
 #define CTC_AMD_NOBLANK 0
@@ -42,7 +42,8 @@ extern "C" {
 int ctc_amd_abi_version(void);
 const char *ctc_amd_error_string(int code);
 
-/* Bytes of device workspace a *_loss_grad call of this shape needs (>= 256). */
+/* Bytes of device workspace a call of this shape needs (>= 256).  No-blank lattices that do
+ * not fit in LDS (long sequences) and the blank-CTC lattice live in this workspace. */
 size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int S);
 
 /* NoBlankCTC.forward (NoBlankCTC.py:129-141) + the gradient autograd would produce

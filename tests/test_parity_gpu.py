@@ -317,11 +317,11 @@ def test_binary_kernel_path_boundaries(dev, shape):
 
 def test_unsupported_shapes_raise(dev):
     import ctc_amd
-    # the T x S lattice of the no-blank kernels lives in LDS (160 KB): beyond it the C ABI
-    # reports "unsupported shape" and the Python layer raises -- never a silent fallback
-    x, lab, Tb, L = synth_noblank(1, 3000, 1, 8, 20)
+    # shapes the kernels do not tile are reported by the C ABI as "unsupported shape" and the
+    # Python layer raises -- never a silent fallback
+    x, y, Tb, L = synth_binary(1, 3000, 1, 8, 20)            # binary lattice must fit in LDS
     with pytest.raises(ctc_amd.CtcAmdError):
-        ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), Tb, L)
+        ctc_amd.binary_ctc_loss(x.to(dev), y.to(dev), Tb, L)
     x, lab, Tb, L = synth_noblank(1, 4, 1, 8, 300)
     with pytest.raises(ctc_amd.CtcAmdError):
         ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), Tb, torch.minimum(L, Tb))
@@ -392,3 +392,18 @@ def test_noblank_posteriors(dev, shape):
         assert np.abs(gamma[b, :int(Tb[b])].sum(axis=1) - 1.0).max() < 1e-5     # a distribution per live step
         assert np.abs(gamma[b, int(Tb[b]):]).max(initial=0.0) == 0.0
         assert np.abs(gamma[b, :, int(L[b]):]).max(initial=0.0) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2000, 2, 50, 20), (700, 3, 300, 40), (900, 2, 20, 100)])
+def test_noblank_long_sequences_use_workspace_lattice(dev, shape):
+    """T x S beyond LDS: the lattice moves to the workspace (ctc_amd_workspace_bytes grows)."""
+    import ctc_amd
+    from ctc_amd import _lib
+    T, B, C, S = shape
+    assert _lib.load().ctc_amd_workspace_bytes(0, T, B, C, S) > 256
+    x, lab, Tb, L = synth_noblank(sum(shape), T, B, C, S, var_T=True)
+    ref = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+    assert_close(r, ref, 2e-5 * max(1.0, 256.0 / B), nll_rtol=2e-5)     # T ~ 1e3: nll ~ 5e3, ulp 5e-4
+    gamma, _ = ctc_amd.noblank_posteriors(x.to(dev), lab.to(dev), Tb.to(dev), L.to(dev))
+    assert np.abs(np_(gamma).sum(axis=2)[0, :int(Tb[0])] - 1.0).max() < 1e-4
