@@ -36,6 +36,11 @@ constexpr int kPipeRows = 12;                               // slots per worker
 constexpr int kPipeMaxT = kPipeWorkers * kPipeRows;         // 168
 constexpr int kSpinLimit = 1 << 20;
 
+// Publish / consume points of the LDS hand-off.  The hardware completes a wave's LDS operations
+// in order, so no wait is needed -- but the COMPILER must not move a row access across the
+// counter access (float rows and int counters do not alias for it).  Zero instructions.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
 // a re-read that must really go to LDS again (another wave writes the row): volatile, but in
 // the LDS address space -- a generic volatile load would become a flat_load sc0 sc1 + vmcnt(0)
 typedef const volatile __attribute__((address_space(3))) float lds_cvfloat;
@@ -92,6 +97,7 @@ __device__ __forceinline__ float lattice_chain_sync(const NoblankParams &p, cons
             __builtin_amdgcn_s_sleep(1);
             seen = *(lds_cvint *)cp;
         }
+        lds_order();                                         // rows are read only after the look
         seen = *(lds_cvint *)cp;                             // for the next look
     };
     auto shift = [&]() {
@@ -120,6 +126,7 @@ __device__ __forceinline__ float lattice_chain_sync(const NoblankParams &p, cons
     for (int j = 0; j < kPrefetch; ++j) { ring[j] = *rd; rd += winc; }
     int i = 1;
     for (; i + kBlockSteps <= Tb; i += kBlockSteps) {
+        lds_order();                                         // row stores above, then the count
         *prog = i;                                           // (every lane, same value: no exec juggling)
         wait_upto(i + kBlockSteps - 1 + kPrefetch);
 #pragma unroll
@@ -130,6 +137,7 @@ __device__ __forceinline__ float lattice_chain_sync(const NoblankParams &p, cons
             step(e);
         }
     }
+    lds_order();
     *prog = i;
     wait_upto(Tb - 1);
 #pragma unroll
@@ -140,6 +148,7 @@ __device__ __forceinline__ float lattice_chain_sync(const NoblankParams &p, cons
             rd += winc;
             step(e);
         }
+    lds_order();
     *prog = Tb;
     __builtin_amdgcn_s_setprio(0);
     return a;
@@ -274,6 +283,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
                                                              // would spill the scalar file
             if (t >= 0 && t < Tb && lane < p.SP)             // (t: wave-uniform)
                 sm.em[t * p.SP + lane] = (lane < L) ? (xv[k] - m[k]) - lsum : kNeg;
+            lds_order();
             if (lane == 0) sm.cnt[u] = r + 1;                // publishes the slot (same wave: in order)
         }
     }
@@ -295,11 +305,13 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
         for (int c = lane; c < p.C; c += kWave)
             if (sm.inv[c] == 0x7fffffff) sm.inv[c] = -1;
         if (lane < p.SP) sm.dup[lane] = (lane < L && sm.inv[k] == lane && n >= 0) ? 1 : 0;
+        lds_order();
         if (lane == 0) sm.dummy[7] = 1.0f;                   // tables ready (same wave: LDS stores in order)
     }
     {
         int spins = 0;
         while (lds_now(sm.dummy + 7) == 0.f && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(4);
+        lds_order();
     }
     int first[CH];
     bool has[CH];
@@ -342,6 +354,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
             while ((*(lds_cvint *)(sm.cnt + kPipeWorkers) < need_a || *(lds_cvint *)(sm.cnt + kPipeWorkers + 1) < need_b) &&
                    ++spins < kSpinLimit)
                 __builtin_amdgcn_s_sleep(8);
+            lds_order();                                     // lattice rows are read only after the look
         }
         if (p.stop < 0) stamp(p, 3 + (2 - gq));             // diagnostic: groups 2,1,0 -> slots 3,4,5
         // gamma_t = softmax_l(alpha_t + beta'_t - e_t): row-normalised posterior (lattice.hpp).
