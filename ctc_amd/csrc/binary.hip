@@ -308,17 +308,64 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
                            [](float x, int) { return x; });
     if (!p.grad) return;
 
-    // P3a: posteriors (rows round-robin over the waves)
     const bool feasible = ok && nll < kInfeasible;
     const int Tlive = feasible ? Tb : 0;
-    if (K == 1) {                                            // S <= 64: four rows per pass, interleaved reductions
-        for (int t0 = w * 4; t0 < Tlive; t0 += kBinWaves * 4) {
+    const float gs = p.grad_scale * invC;
+
+    if (K == 1) {
+        // P3 (S <= 64): every wave finishes its OWN rows, four at a time, with no further barrier.
+        //   gamma rows by posterior_rows4 (wave-local LDS), then G = gamma . Y on
+        //   v_mfma_f32_4x4x1 (16 blocks of 4x4, K = 1 per instruction): block = lane>>2 and
+        //   column-in-block = lane&3 make the output column equal the lane and put the four rows
+        //   in the four accumulator registers -- exactly the layout of the resident rows, so
+        //   the gradient needs no LDS transpose.  A = gamma[row lane&3][l], B = Y[l][lane + 64 j].
+#pragma unroll
+        for (int r0 = 0; r0 < kBinRows; r0 += 4) {
             int tt[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tt[k] = t0 + k < Tlive ? t0 + k : -1;
-            posterior_rows4(sm.al, sm.be, sm.em, tt, L, p.SP, 1.0f);
+            for (int i = 0; i < 4; ++i) {
+                const int t = w * kBinRows + r0 + i;
+                tt[i] = (r0 + i < kBinRows && t < Tlive) ? t : -1;
+            }
+            const int t_first = w * kBinRows + r0;
+            if (t_first >= p.T) break;                       // wave-uniform
+            f32x4 acc[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t_first < Tlive) {                           // wave-uniform: at least one live row
+                posterior_rows4(sm.al, sm.be, sm.em, tt, L, p.SP, 1.0f);
+                const int ti = tt[lane & 3];
+                const float *arow = sm.be + (ti >= 0 ? ti : 0) * p.SP;
+                for (int l = 0; l < L; ++l) {
+                    const float a = ti >= 0 ? arow[l] : 0.f;
+                    const float *yl = sm.ys + l * PD + lane;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, yl[64 * j], acc[j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = w * kBinRows + r0 + i;
+                if (r0 + i >= kBinRows || t >= p.T) break;   // wave-uniform
+                float *g = p.grad + ((int64_t)t * p.B + b) * p.C;
+                const bool live = t < Tlive;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int c = lane + 64 * j;
+                    if (c < p.C) {
+                        const float pr = v[r0 + i][j];       // sigmoid(x), kept from P1a
+                        const float pq = pr * (1.0f - pr);
+                        stream_store(&g[c], live ? gs * (pr - acc[j][i]) * (pq * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f))) : 0.f);
+                    }
+                }
+            }
         }
-    } else {
+        return;
+    }
+
+    // K > 1 (S > 64): posteriors row by row, G on 16x16 MFMA tiles through the D image
+    {
         const int G = posterior_group(p.SP), per = kWave / G, sub = lane / G;
         for (int t0 = w * per; t0 < Tlive; t0 += kBinWaves * per)
             posterior_row<false>(sm.al, sm.be, sm.em, nullptr, nullptr, t0 + sub, t0 + sub < Tlive, L, p.SP, G);
@@ -342,7 +389,6 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
     __syncthreads();
 
     // P3c: gradient rows from the resident registers
-    const float gs = p.grad_scale * invC;
 #pragma unroll
     for (int r = 0; r < kBinRows; ++r) {
         const int t = w * kBinRows + r;
