@@ -17,6 +17,7 @@
 // (lanes over c, DPP wave reduction).  Chains and posteriors as in noblank.hip.  The
 // gradient pass contracts gamma_t with the staged y per element and re-reads x (L2).
 #include <cstdlib>
+#include <type_traits>
 
 #include "lattice.hpp"
 #include "launch.hpp"
@@ -29,6 +30,7 @@ struct BinaryParams {
     const float *y;
     const int64_t *in_len, *tgt_len;
     int T, B, C, S, SP, CP;      // CP: padded row pitch of the staged y / row buffers
+    int stop;                    // diagnostics: < 0 selects the wave that stamps phase boundaries
     float loss_scale, grad_scale;
     float *nll, *loss, *grad;
     unsigned *counter;
@@ -197,12 +199,14 @@ constexpr int kBinRows = 160 / kBinWaves;                    // rows resident pe
 
 struct BinaryMfmaSmem {
     float *em, *al, *be, *dummy, *q, *ys, *dimg;
+    int *prog;                                               // [2] completed steps of the alpha / beta' scans
     __device__ BinaryMfmaSmem(float *base, int T, int Tpad, int SP, int PD)
     {
         em = base + kPrefetch * SP;
         al = em + (size_t)(T + kPrefetch) * SP;
         be = al + (size_t)T * SP;
         dummy = be + (size_t)T * SP;
+        prog = reinterpret_cast<int *>(dummy + 4);           // (dummy[0..3]: idle-lane slots)
         q = dummy + 8;
         ys = q + Tpad;
         dimg = ys + (size_t)SP * PD;
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
     extern __shared__ float4 smem_raw[];
     const BinaryMfmaSmem sm(reinterpret_cast<float *>(smem_raw), p.T, Tpad, p.SP, PD);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    stamp(p, 0);
     const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
 
     // rows of this wave, unconditional clamped loads (stay resident until P3c)
@@ -243,12 +248,13 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
         const int l = i / PD, c = i - l * PD;
         sm.ys[i] = (l < p.S && c < p.C) ? yb[l * p.C + c] : 0.f;
     }
-    if (tid < 8) sm.dummy[tid] = 0.f;
+    if (tid < 8) sm.dummy[tid] = 0.f;                        // (also zeroes the two progress counters)
     for (int i = tid; i < kPrefetch * p.SP; i += kBinThreads) {
         sm.em[i - kPrefetch * p.SP] = kNeg;
         sm.em[p.T * p.SP + i] = kNeg;
     }
 
+    stamp(p, 1);
     // P1a: elementwise BCE logs -> D image, Q
 #pragma unroll
     for (int r = 0; r < kBinRows; ++r) {
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
         q = wave_sum(q);
         if (lane == 0) sm.q[t] = q;
     }
+    stamp(p, 2);
     __syncthreads();
 
     // P1b: E = D . Y^T (16x16 tiles, K = C in steps of 4)
@@ -287,30 +294,43 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
             if (t < Tb && lrow < p.SP) sm.em[t * p.SP + lrow] = lrow < L ? (acc[j] + sm.q[t]) * invC : kNeg;
         }
     }
+    stamp(p, 3);
     __syncthreads();
+    stamp(p, 4);
 
-    // P2: alpha / beta' chains
+    // P2: alpha / beta' chains (waves 0 and 1).  S <= 64: they publish their progress and NO
+    // barrier follows -- every wave then finishes its own rows as soon as both scans have
+    // passed them (middle of the sequence first), overlapping the gradient with the scans.
+    const float gs = p.grad_scale * invC;
     if (Tb > 0) {
         const bool rot = p.SP <= 63 * K;
+        int *pa = K == 1 ? sm.prog : nullptr, *pb = K == 1 ? sm.prog + 1 : nullptr;
         if (w == 0) {
-            if (rot) lattice_chain<K, true, true>(sm.em, sm.al, sm.dummy, Tb, L, p.SP);
-            else lattice_chain<K, true, false>(sm.em, sm.al, sm.dummy, Tb, L, p.SP);
+            if (rot) lattice_chain<K, true, true>(sm.em, sm.al, sm.dummy, Tb, L, p.SP, pa);
+            else lattice_chain<K, true, false>(sm.em, sm.al, sm.dummy, Tb, L, p.SP, pa);
         } else if (w == 1 && p.grad) {
-            if (rot) lattice_chain<K, false, true>(sm.em, sm.be, sm.dummy, Tb, L, p.SP);
-            else lattice_chain<K, false, false>(sm.em, sm.be, sm.dummy, Tb, L, p.SP);
+            if (rot) lattice_chain<K, false, true>(sm.em, sm.be, sm.dummy, Tb, L, p.SP, pb);
+            else lattice_chain<K, false, false>(sm.em, sm.be, sm.dummy, Tb, L, p.SP, pb);
         }
     }
-    __syncthreads();
-
-    const float nll = ok ? -sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;
-    if (w == kBinWaves - 1)
-        publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
-                           [](float x, int) { return x; });
-    if (!p.grad) return;
-
-    const bool feasible = ok && nll < kInfeasible;
-    const int Tlive = feasible ? Tb : 0;
-    const float gs = p.grad_scale * invC;
+    stamp(p, 5);
+    typedef const volatile __attribute__((address_space(3))) int lds_cvint;
+    if (K != 1) __syncthreads();
+    if (w == kBinWaves - 1 || !p.grad) {
+        // nll / batch mean by the last wave (it owns the fewest rows): wait for the alpha scan
+        if (K == 1 && Tb > 0) {
+            int spins = 0;
+            while (*(lds_cvint *)sm.prog < Tb && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
+            lds_order();
+        }
+        if (w == kBinWaves - 1) {
+            const float nll = ok ? -sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;
+            publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
+                               [](float x, int) { return x; });
+        }
+        if (!p.grad) return;
+    }
+    const int Tlive = Tb;                                    // ok <=> an alignment exists (L_b <= T_b)
 
     if (K == 1) {
         // P3 (S <= 64): every wave finishes its OWN rows, four at a time, with no further barrier.
@@ -319,8 +339,8 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
         //   column-in-block = lane&3 make the output column equal the lane and put the four rows
         //   in the four accumulator registers -- exactly the layout of the resident rows, so
         //   the gradient needs no LDS transpose.  A = gamma[row lane&3][l], B = Y[l][lane + 64 j].
-#pragma unroll
-        for (int r0 = 0; r0 < kBinRows; r0 += 4) {
+        auto group = [&](auto R0) {
+            constexpr int r0 = decltype(R0)::value;
             int tt[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -328,20 +348,36 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
                 tt[i] = (r0 + i < kBinRows && t < Tlive) ? t : -1;
             }
             const int t_first = w * kBinRows + r0;
-            if (t_first >= p.T) break;                       // wave-uniform
+            if (t_first >= p.T) return;                      // wave-uniform
             f32x4 acc[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t_first < Tlive) {                           // wave-uniform: at least one live row
+                int t_hi = t_first;                          // the scans must have passed rows t_first..t_hi
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t_hi = tt[i] >= 0 ? tt[i] : t_hi;
+                int spins = 0;
+                while ((*(lds_cvint *)sm.prog < t_hi + 1 || *(lds_cvint *)(sm.prog + 1) < Tlive - t_first) &&
+                       ++spins < (1 << 20))
+                    __builtin_amdgcn_s_sleep(8);
+                lds_order();
                 posterior_rows4(sm.al, sm.be, sm.em, tt, L, p.SP, 1.0f);
                 const int ti = tt[lane & 3];
                 const float *arow = sm.be + (ti >= 0 ? ti : 0) * p.SP;
-                for (int l = 0; l < L; ++l) {
-                    const float a = ti >= 0 ? arow[l] : 0.f;
-                    const float *yl = sm.ys + l * PD + lane;
+                const float amask = ti >= 0 ? 1.f : 0.f;
+                for (int l0 = 0; l0 < L; l0 += 4) {          // SP % 4 == 0; gamma and Y rows beyond L / S are 0
+                    float fa[4], fy[4][CH];
 #pragma unroll
-                    for (int j = 0; j < CH; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, yl[64 * j], acc[j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {            // loads first: LDS latency once per batch
+                        fa[i] = arow[l0 + i] * amask;
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) fy[i][j] = sm.ys[(l0 + i) * PD + lane + 64 * j];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < CH; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(fa[i], fy[i][j], acc[j], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -360,7 +396,20 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
                     }
                 }
             }
+        };
+        // rows nearest the middle of the sequence are ready first: walk this wave's groups in that order
+        static_assert(kBinRows > 8 && kBinRows <= 12, "three groups of four rows per wave");
+        using std::integral_constant;
+        if (w * kBinRows * 2 + kBinRows < Tlive) {           // wave in the first half: highest rows first
+            group(integral_constant<int, 8>{});
+            group(integral_constant<int, 4>{});
+            group(integral_constant<int, 0>{});
+        } else {
+            group(integral_constant<int, 0>{});
+            group(integral_constant<int, 4>{});
+            group(integral_constant<int, 8>{});
         }
+        stamp(p, 7);
         return;
     }
 
@@ -446,6 +495,8 @@ extern "C" int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_
     p.loss_scale = loss_scale; p.grad_scale = grad_scale;
     p.nll = nll; p.loss = loss; p.grad = grad;
     p.counter = static_cast<unsigned *>(workspace);
+    static const int debug_stop = getenv("CTC_AMD_DEBUG_STOP") ? atoi(getenv("CTC_AMD_DEBUG_STOP")) : 0;
+    p.stop = debug_stop < 0 ? debug_stop : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // fast path: MFMA contractions, rows resident (T <= 160, C <= 256, images fit in LDS)
     if (T <= kBinRows * kBinWaves && C <= 256 && !getenv("CTC_AMD_BINARY_VALU")) {

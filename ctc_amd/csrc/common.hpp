@@ -26,6 +26,12 @@ __device__ __forceinline__ void stream_store(float4 *p, float4 v)
     __builtin_nontemporal_store(n, reinterpret_cast<native4 *>(p));
 }
 
+// Publish / consume points of LDS hand-offs between waves of a workgroup.  The hardware
+// completes a wave's LDS operations in order, so no wait is needed -- but the COMPILER must not
+// move a row access across the counter access (float rows and int counters do not alias for
+// it).  Zero instructions.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2).  Rows of
 // neighbouring samples share 128-byte lines (a row is C*4 bytes, rarely a multiple of 128),
 // so consecutive samples are mapped onto the SAME XCD: the straddling lines are then fetched
@@ -190,6 +196,20 @@ __device__ __forceinline__ float lse2(float a, float b)
 __device__ __forceinline__ int load_label(const void *p, int is64, int64_t i)
 {
     return static_cast<const int32_t *>(p)[is64 ? 2 * i : i];
+}
+
+// Diagnostics only (CTC_AMD_DEBUG_STOP = -(wave+1)): that wave of workgroup 0 stamps
+// (s_memtime, s_memrealtime) pairs into workspace bytes [64,256) at phase boundaries
+// (tools/stamps.py reads them).  Never executes in a normal run (p.stop == 0).
+template <typename P>
+__device__ __forceinline__ void stamp(const P &p, int slot)
+{
+    if (p.stop >= 0) return;
+    if (blockIdx.x == 0 && wave_id() == -p.stop - 1 && lane_id() == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
+        o[0] = __builtin_amdgcn_s_memtime();
+        o[1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // Deterministic batch reduction by the LAST workgroup to finish its nll (in-launch

@@ -29,8 +29,11 @@ __device__ __forceinline__ float vmax(float a, float b)
 // FWD: t = 0..Tb-1 from state 0; !FWD: t = Tb-1..0 from state L-1.
 // ROT: lane 63 is idle (SP <= 63*K), so a wave rotate needs no fill value.
 // Serial dependency per step: dpp -> sub -> mul -> exp -> add -> log -> fma -> add.
+// `prog` (optional, LDS): the number of completed steps is published there every kPrefetch
+// steps, so that other waves can start on rows both scans have passed (binary.hip).
 template <int K, bool FWD, bool ROT>
-__device__ __forceinline__ void lattice_chain(const float *em, float *out, float *dummy, int Tb, int L, int SP)
+__device__ __forceinline__ void lattice_chain(const float *em, float *out, float *dummy, int Tb, int L, int SP,
+                                              int *prog = nullptr)
 {
     const int l0 = lane_id() * K;
     const bool act = l0 < SP;                       // whole lane inside or outside the row
@@ -82,6 +85,7 @@ __device__ __forceinline__ void lattice_chain(const float *em, float *out, float
     }
     int i = 1;
     for (; i + kPrefetch <= Tb; i += kPrefetch) {           // branch-free body
+        if (prog) { lds_order(); *prog = i; }               // (wave-uniform; every lane, same value)
 #pragma unroll
         for (int j = 0; j < kPrefetch; ++j) {
             float e[K];
@@ -94,6 +98,7 @@ __device__ __forceinline__ void lattice_chain(const float *em, float *out, float
 #pragma unroll
     for (int j = 0; j < kPrefetch; ++j)                      // tail: ring[j] holds row i+j
         if (i + j < Tb) step(ring[j]);
+    if (prog) { lds_order(); *prog = Tb; }
 }
 
 // Posterior row: gamma_t(l) = exp(alpha_t(l) + beta'_t(l) - e_t(l)) / sum_l' (same), written

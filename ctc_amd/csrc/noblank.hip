@@ -254,17 +254,6 @@ __device__ __forceinline__ void build_label_tables(const NoblankParams &p, const
     if (tid < p.SP) sm.dup[tid] = (tid < L && sm.inv[sm.lab[tid]] == tid && sm.nxt[tid] >= 0) ? 1 : 0;
 }
 
-// diagnostic builds only (CTC_AMD_DEBUG_STOP < 0); never executes in a normal run
-__device__ __forceinline__ void stamp(const NoblankParams &p, int slot)
-{
-    if (p.stop >= 0) return;
-    if (blockIdx.x == 0 && wave_id() == -p.stop - 1 && lane_id() == 0) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
-        o[0] = __builtin_amdgcn_s_memtime();
-        o[1] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
 // CH = 0: generic rows (C > 256).  GLB: lattice in global memory (T x S beyond LDS; slower:
 // the chains then prefetch their rows from L2) -- completeness path for long sequences.
 template <int K, int CH, bool GLB = false>

@@ -36,11 +36,6 @@ constexpr int kPipeRows = 12;                               // slots per worker
 constexpr int kPipeMaxT = kPipeWorkers * kPipeRows;         // 168
 constexpr int kSpinLimit = 1 << 20;
 
-// Publish / consume points of the LDS hand-off.  The hardware completes a wave's LDS operations
-// in order, so no wait is needed -- but the COMPILER must not move a row access across the
-// counter access (float rows and int counters do not alias for it).  Zero instructions.
-__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
-
 // a re-read that must really go to LDS again (another wave writes the row): volatile, but in
 // the LDS address space -- a generic volatile load would become a flat_load sc0 sc1 + vmcnt(0)
 typedef const volatile __attribute__((address_space(3))) float lds_cvfloat;

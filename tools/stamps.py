@@ -15,7 +15,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402
 
-wl = bench.Workload("noblank", 256, 256, torch.device("cuda:0"), 0)
+wl = bench.Workload(sys.argv[1] if len(sys.argv) > 1 else "noblank", 256, 256, torch.device("cuda:0"), 0)
 ws = wl.new_workspace()
 loss = torch.zeros(4, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
