@@ -227,11 +227,117 @@ __global__ __launch_bounds__(128) void blank_chain_kernel(BlankParams p)
 // ---- K2: gamma -> gradient rows ----------------------------------------------------------------
 constexpr int kGradWaves = 4;
 
-// VEC4: C % 4 == 0 and 16-byte aligned rows -> the dense part moves float4 per lane (4x fewer
-// memory instructions); the row's loads are all issued before the reductions so their latency
-// hides behind them.  kMaxV4 float4 per lane cover C <= 1024 in registers.
 constexpr int kMaxV4 = 4;
 
+// One (t,b) row of work for a wave of blank_grad_kernel: everything it loads from HBM.
+template <int K>
+struct BlankRow {
+    float4 xr[kMaxV4];
+    float al[K], be[K], em[K];
+    int t, b, Tb, L;
+    bool live;
+};
+
+template <int K, bool VEC4>
+__device__ __forceinline__ void blank_row_load(const BlankParams &p, int idx, BlankRow<K> &r)
+{
+    const int lane = lane_id();
+    r.t = idx / p.B;
+    r.b = idx - r.t * p.B;                                   // consecutive waves -> consecutive b: contiguous rows
+    const bool ok = blank_sample_ok(p, r.b, r.Tb, r.L);
+    r.live = ok && r.t < r.Tb && p.nll[r.b] < 3.0e38f;       // beyond T_b, or no alignment: zero row
+    if (!r.live) return;                                     // wave-uniform
+    const int64_t off = ((int64_t)r.b * p.T + r.t) * p.NSP + lane * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { r.al[k] = p.al[off + k]; r.be[k] = p.be[off + k]; r.em[k] = p.em[off + k]; }
+    if (VEC4) {
+        const float *row = p.lp + (int64_t)r.t * p.st + (int64_t)r.b * p.sb;
+#pragma unroll
+        for (int i = 0; i < kMaxV4; ++i) {
+            const int q = lane + kWave * i;
+            r.xr[i] = q < (p.C >> 2) ? reinterpret_cast<const float4 *>(row)[q] : make_float4(0, 0, 0, 0);
+        }
+    }
+}
+
+template <int K, bool VEC4>
+__device__ __forceinline__ void blank_row_finish(const BlankParams &p, const BlankRow<K> &r, float *occ, float *gam)
+{
+    const int lane = lane_id(), s0 = lane * K;
+    float *g = p.grad + ((int64_t)r.t * p.B + r.b) * p.C;
+    if (!r.live) {
+        if (VEC4) {
+            for (int q = lane; q < (p.C >> 2); q += kWave) stream_store(reinterpret_cast<float4 *>(g) + q, make_float4(0, 0, 0, 0));
+        } else {
+            for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], 0.f);
+        }
+        return;
+    }
+    const int n = 2 * r.L + 1;
+    const int *cls = p.cls + r.b * p.NSP, *nxt = p.nxt + r.b * p.NSP, *first = p.first + r.b * p.NSP;
+    float v[K];
+    float m = kNegB;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = s0 + k < n ? r.al[k] + r.be[k] - r.em[k] : kNegB;
+        m = fmaxf(m, v[k]);
+    }
+    m = wave_max(m);
+    float ssum = 0.f, blank_part = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = s0 + k < n ? __builtin_amdgcn_exp2f(v[k] - m) : 0.f;     // lattice is in log2 units
+        ssum += v[k];
+        if (((s0 + k) & 1) == 0) blank_part += v[k];
+    }
+    ssum = wave_sum(ssum);
+    blank_part = wave_sum(blank_part);
+    const float inv = 1.0f / ssum;
+#pragma unroll
+    for (int k = 0; k < K; ++k) gam[s0 + k] = v[k] * inv;            // wave-local LDS, in order
+    // occupancy per class: blank from the reduction, labels folded along the repeat chain
+    if (lane == 0) occ[p.blank] = blank_part * inv;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int s = s0 + k;
+        if (first[s]) {                                       // label states only; repeats are chained
+            float tot = gam[s];
+            for (int q = nxt[s]; q >= 0; q = nxt[q]) tot += gam[q];
+            occ[cls[s]] = tot;
+        }
+    }
+    const float gs = p.grad_scale / (float)(r.L > 1 ? r.L : 1);
+    if (VEC4) {
+#pragma unroll
+        for (int i = 0; i < kMaxV4; ++i) {
+            const int q = lane + kWave * i;
+            if (q < (p.C >> 2)) {
+                const float4 o = reinterpret_cast<const float4 *>(occ)[q];
+                float4 out;
+                out.x = (fast_exp(r.xr[i].x) - o.x) * gs;
+                out.y = (fast_exp(r.xr[i].y) - o.y) * gs;
+                out.z = (fast_exp(r.xr[i].z) - o.z) * gs;
+                out.w = (fast_exp(r.xr[i].w) - o.w) * gs;
+                stream_store(reinterpret_cast<float4 *>(g) + q, out);
+            }
+        }
+    } else {
+        const float *row = p.lp + (int64_t)r.t * p.st + (int64_t)r.b * p.sb;
+        for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], (fast_exp(row[c]) - occ[c]) * gs);
+    }
+    // un-set only what this row touched
+    if (lane == 0) occ[p.blank] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int s = s0 + k;
+        if ((s & 1) && s < n) occ[cls[s]] = 0.f;
+    }
+}
+
+// VEC4: C % 4 == 0 and 16-byte aligned rows -> the dense part moves float4 per lane (4x fewer
+// memory instructions).  Rows are double-buffered: the loads of a wave's NEXT row (lattice
+// triples + the whole log-prob row, kMaxV4 float4 per lane cover C <= 1024) are in flight while
+// the current row is reduced and written.
 template <int K, bool VEC4>
 __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankParams p, int total_rows)
 {
@@ -241,90 +347,17 @@ __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankPar
     float *occ = reinterpret_cast<float *>(s_buf4) + (size_t)w * (C4 + p.NSP);
     float *gam = occ + C4;
     for (int c = lane; c < C4; c += kWave) occ[c] = 0.f;
-    const int s0 = lane * K;
-    for (int idx = blockIdx.x * kGradWaves + w; idx < total_rows; idx += gridDim.x * kGradWaves) {
-        const int t = idx / p.B, b = idx - t * p.B;          // consecutive waves -> consecutive b: contiguous rows
-        int Tb, L;
-        const bool ok = blank_sample_ok(p, b, Tb, L);
-        float *g = p.grad + ((int64_t)t * p.B + b) * p.C;
-        const float nllb = p.nll[b];
-        if (!ok || t >= Tb || !(nllb < 3.0e38f)) {           // beyond T_b, or no alignment: zero row
-            if (VEC4) {
-                for (int q = lane; q < (p.C >> 2); q += kWave) stream_store(reinterpret_cast<float4 *>(g) + q, make_float4(0, 0, 0, 0));
-            } else {
-                for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], 0.f);
-            }
-            continue;
-        }
-        const int n = 2 * L + 1;
-        const int64_t off = ((int64_t)b * p.T + t) * p.NSP + s0;
-        const int *cls = p.cls + b * p.NSP, *nxt = p.nxt + b * p.NSP, *first = p.first + b * p.NSP;
-        const float *row = p.lp + (int64_t)t * p.st + (int64_t)b * p.sb;
-        // all loads of the row first
-        float4 xr[kMaxV4];
-        if (VEC4) {
-#pragma unroll
-            for (int i = 0; i < kMaxV4; ++i) {
-                const int q = lane + kWave * i;
-                xr[i] = q < (p.C >> 2) ? reinterpret_cast<const float4 *>(row)[q] : make_float4(0, 0, 0, 0);
-            }
-        }
-        float v[K];
-        float m = kNegB;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            v[k] = s0 + k < n ? p.al[off + k] + p.be[off + k] - p.em[off + k] : kNegB;
-            m = fmaxf(m, v[k]);
-        }
-        m = wave_max(m);
-        float ssum = 0.f, blank_part = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            v[k] = s0 + k < n ? __builtin_amdgcn_exp2f(v[k] - m) : 0.f;     // lattice is in log2 units
-            ssum += v[k];
-            if (((s0 + k) & 1) == 0) blank_part += v[k];
-        }
-        ssum = wave_sum(ssum);
-        blank_part = wave_sum(blank_part);
-        const float inv = 1.0f / ssum;
-#pragma unroll
-        for (int k = 0; k < K; ++k) gam[s0 + k] = v[k] * inv;        // wave-local LDS, in order
-        // occupancy per class: blank from the reduction, labels folded along the repeat chain
-        if (lane == 0) occ[p.blank] = blank_part * inv;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int s = s0 + k;
-            if (first[s]) {                                   // label states only; repeats are chained
-                float tot = gam[s];
-                for (int q = nxt[s]; q >= 0; q = nxt[q]) tot += gam[q];
-                occ[cls[s]] = tot;
-            }
-        }
-        const float gs = p.grad_scale / (float)(L > 1 ? L : 1);
-        if (VEC4) {
-#pragma unroll
-            for (int i = 0; i < kMaxV4; ++i) {
-                const int q = lane + kWave * i;
-                if (q < (p.C >> 2)) {
-                    const float4 o = reinterpret_cast<const float4 *>(occ)[q];
-                    float4 r;
-                    r.x = (fast_exp(xr[i].x) - o.x) * gs;
-                    r.y = (fast_exp(xr[i].y) - o.y) * gs;
-                    r.z = (fast_exp(xr[i].z) - o.z) * gs;
-                    r.w = (fast_exp(xr[i].w) - o.w) * gs;
-                    stream_store(reinterpret_cast<float4 *>(g) + q, r);
-                }
-            }
-        } else {
-            for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], (fast_exp(row[c]) - occ[c]) * gs);
-        }
-        // un-set only what this row touched
-        if (lane == 0) occ[p.blank] = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int s = s0 + k;
-            if ((s & 1) && s < n) occ[cls[s]] = 0.f;
-        }
+    const int stride = gridDim.x * kGradWaves;
+    int idx = blockIdx.x * kGradWaves + w;
+    if (idx >= total_rows) return;
+    BlankRow<K> ra, rb;
+    blank_row_load<K, VEC4>(p, idx, ra);
+    for (; idx < total_rows; idx += 2 * stride) {
+        const bool has_b = idx + stride < total_rows;        // wave-uniform
+        if (has_b) blank_row_load<K, VEC4>(p, idx + stride, rb);
+        blank_row_finish<K, VEC4>(p, ra, occ, gam);
+        if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4>(p, idx + 2 * stride, ra);
+        if (has_b) blank_row_finish<K, VEC4>(p, rb, occ, gam);
     }
 }
 
