@@ -43,6 +43,22 @@ def _workspace(variant, T, B, C, S, device):
     return ws
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on_device(dev):
+    """device guard only when the tensor's device is not already current (saves a few us per call)"""
+    return _NULL if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
 def _require_hip(x, name):
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise _lib.CtcAmdError(
@@ -62,6 +78,8 @@ def _lengths(v, B, lo_name, device, hi, lo=1):
         h = v.detach().cpu()
         if h.numel() and (int(h.min()) < lo or int(h.max()) > hi):
             raise ValueError("ctc_amd: %s must lie in [%d, %d]" % (lo_name, lo, hi))
+    if v.dtype == torch.int64 and v.device == device and v.is_contiguous():
+        return v                                    # the usual case (train.py:397-399): nothing to convert
     return v.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
 
 
@@ -98,11 +116,13 @@ def _launch(variant, x, targets, in_len, tgt_len, want_grad, batch_total, blank=
     if variant == _lib.BINARY:
         if targets.shape[2] != C:
             raise ValueError("ctc_amd: binary targets last dim %d != C %d" % (targets.shape[2], C))
-        tg = targets.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+        tg = targets if (targets.device == dev and targets.dtype == torch.float32 and targets.is_contiguous()) \
+            else targets.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
     else:
         if targets.dtype not in (torch.int32, torch.int64):
             targets = targets.long()
-        tg = targets.to(device=dev, non_blocking=True).contiguous()
+        tg = targets if (targets.device == dev and targets.is_contiguous()) else \
+            targets.to(device=dev, non_blocking=True).contiguous()
     il = _lengths(in_len, B, "input_lengths", dev, T)
     tl = _lengths(tgt_len, B, "target_lengths", dev, S, lo=0 if variant == _lib.BLANK else 1)
     total = B if batch_total is None else int(batch_total)
@@ -110,7 +130,7 @@ def _launch(variant, x, targets, in_len, tgt_len, want_grad, batch_total, blank=
     loss = torch.empty((), dtype=torch.float32, device=dev)
     grad = torch.empty((T, B, C), dtype=torch.float32, device=dev) if want_grad else None
     lib = _lib.load()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws = _workspace(variant, T, B, C, S, dev)
         stream = _stream_handle(dev)
         gp = grad.data_ptr() if want_grad else None
@@ -144,8 +164,10 @@ def _scaled_grad(ctx, gout):
         x, targets = ctx.saved_tensors
         variant, batch_total, blank = ctx.meta
         _, _, grad = _launch(variant, x, targets, ctx.lens[0], ctx.lens[1], True, batch_total, blank)
-    g = gout.detach().to(device=grad.device, dtype=torch.float32).contiguous()
-    with torch.cuda.device(grad.device):
+    g = gout.detach()
+    if g.dtype != torch.float32 or g.device != grad.device or not g.is_contiguous():
+        g = g.to(device=grad.device, dtype=torch.float32).contiguous()
+    with _on_device(grad.device):
         rc = _lib.load().ctc_amd_scale_grad(grad.data_ptr(), g.data_ptr(), grad.numel(),
                                             _stream_handle(grad.device))
     _lib.check(rc, "ctc_amd_scale_grad")
