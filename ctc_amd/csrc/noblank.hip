@@ -376,6 +376,8 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
 }  // namespace ctc
 
 #include "noblank_pipe.hpp"
+#include "noblank_xr.hpp"
+#include "noblank_r16.hpp"
 
 namespace ctc {
 
@@ -461,7 +463,45 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
             return n;
         }();
-        if (B > cus && 2 * smem <= kMaxLds) {                // more samples than CUs: two workgroups per CU
+        // extended-range linear lattice (noblank_xr.hpp) wherever its 8-byte cells fit
+        static const bool no_xr = getenv("CTC_AMD_NOXR") != nullptr;
+        const size_t xsmem = xr_smem_bytes(T, p.SP, C);
+        const bool dual = B > cus && 2 * smem <= kMaxLds;    // more samples than CUs: two workgroups per CU
+        // lean four-rows-per-wave workers (noblank_r16.hpp): 8-byte aligned rows, S <= 31
+        static const bool no_r16 = getenv("CTC_AMD_NOR16") != nullptr;
+        static const bool force_r16 = getenv("CTC_AMD_R16_ALWAYS") != nullptr;
+        const bool aligned = C % 2 == 0 && stride_t % 2 == 0 && stride_b % 2 == 0 &&
+                             reinterpret_cast<uintptr_t>(x) % 8 == 0 && reinterpret_cast<uintptr_t>(grad) % 8 == 0;
+        const size_t rsmem = r16_smem_bytes(T, p.SP, C);
+        if (!no_r16 && aligned && p.SP <= 31 && rsmem <= kMaxLds && (!dual || force_r16)) {
+            switch ((C + 31) / 32) {
+                case 1: return launch<noblank_r16_kernel<1>>(grid, block, rsmem, s, p);
+                case 2: return launch<noblank_r16_kernel<2>>(grid, block, rsmem, s, p);
+                case 3: return launch<noblank_r16_kernel<3>>(grid, block, rsmem, s, p);
+                case 4: return launch<noblank_r16_kernel<4>>(grid, block, rsmem, s, p);
+                case 5: return launch<noblank_r16_kernel<5>>(grid, block, rsmem, s, p);
+                case 6: return launch<noblank_r16_kernel<6>>(grid, block, rsmem, s, p);
+                case 7: return launch<noblank_r16_kernel<7>>(grid, block, rsmem, s, p);
+                default: return launch<noblank_r16_kernel<8>>(grid, block, rsmem, s, p);
+            }
+        }
+        if (!no_xr && xsmem <= kMaxLds && (!dual || 2 * xsmem <= kMaxLds)) {
+            if (dual) {
+                switch (ch) {
+                    case 1: return launch<noblank_xr_kernel<1, true>>(grid, block, xsmem, s, p);
+                    case 2: return launch<noblank_xr_kernel<2, true>>(grid, block, xsmem, s, p);
+                    case 3: return launch<noblank_xr_kernel<3, true>>(grid, block, xsmem, s, p);
+                    default: return launch<noblank_xr_kernel<4, true>>(grid, block, xsmem, s, p);
+                }
+            }
+            switch (ch) {
+                case 1: return launch<noblank_xr_kernel<1, false>>(grid, block, xsmem, s, p);
+                case 2: return launch<noblank_xr_kernel<2, false>>(grid, block, xsmem, s, p);
+                case 3: return launch<noblank_xr_kernel<3, false>>(grid, block, xsmem, s, p);
+                default: return launch<noblank_xr_kernel<4, false>>(grid, block, xsmem, s, p);
+            }
+        }
+        if (dual) {
             switch (ch) {
                 case 1: return launch<noblank_pipelined_kernel<1, true>>(grid, block, smem, s, p);
                 case 2: return launch<noblank_pipelined_kernel<2, true>>(grid, block, smem, s, p);

@@ -1,0 +1,324 @@
+// "Sixteen-lane rows": the pipelined no-blank kernel with a lean worker (included by noblank.hip).
+//
+// Chains and hand-off are those of noblank_xr.hpp (extended-range linear lattice).  What changes is
+// how the 14 worker waves hold their rows of x.  A single wave issues at most one instruction
+// every ~4.4 cycles whatever its kind (tools/micro/issue_rate.hip), so a worker's time is its
+// INSTRUCTION COUNT; the one-row-per-wave layout of noblank_pipe.hpp / noblank_xr.hpp spends
+// ~250 instructions per row (two six-step whole-wave reductions, scalar bookkeeping per row,
+// class-table lookups, folding of repeated labels).  Here a wave works on FOUR rows at a time,
+// one row per 16-lane DPP row, each lane holding 2*CH2 elements as float2 pairs:
+//
+//   * loads / stores are 8-byte (global_load/store_dwordx2): 128 contiguous bytes per row per
+//     instruction, CH2 instructions per four rows instead of 3 per row;
+//   * row max / sum are serial over the lane's own elements plus a FOUR-step DPP all-reduce that
+//     serves the four rows at once and leaves the result in every lane (no readlane, no scalar
+//     per-row state: t, 1/sum, liveness are per-lane vectors);
+//   * the emission gather x[t, lab_l] goes through a small LDS staging tile (the four raw rows
+//     are written once, the 4 x S gathered values come back with two ds_read_b32);
+//   * in the gradient pass the same tile becomes the class-occupancy tile: it is zeroed, the
+//     scaled posteriors are scattered into it with LDS float atomics (ds_add_f32, repeated
+//     labels simply add up -- no class tables, no duplicate folding), and read back 8 bytes per
+//     lane next to the resident exp(x - max) values.
+//
+// About 45 instructions per row instead of ~250.  Needs C even (8-byte aligned rows), C <= 256,
+// S <= 31, T <= 168 and 35 KB more LDS than noblank_xr.hpp (one workgroup per CU).
+#pragma once
+
+namespace ctc {
+
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+#define CTC_ROW16(OP)                                                                   \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"   \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"       \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"            \
+    "s_nop 1"
+// all-reduce inside each 16-lane DPP row, result in every lane: four VALU instructions
+__device__ __forceinline__ void row16_allmax(float &v) { asm volatile(CTC_ROW16("v_max_f32_dpp") : "+v"(v)); }
+__device__ __forceinline__ void row16_allsum(float &v) { asm volatile(CTC_ROW16("v_add_f32_dpp") : "+v"(v)); }
+__device__ __forceinline__ void row16_allmax(int &v) { asm volatile(CTC_ROW16("v_max_i32_dpp") : "+v"(v)); }
+
+struct R16Smem {
+    cell_t *em, *al, *be;
+    float *dummy, *stage;
+    int *cnt, *lab, *occ;
+    __device__ R16Smem(float *base, int T, int SP, int RP)
+    {
+        cell_t *lat = reinterpret_cast<cell_t *>(base);
+        em = lat + kPrefetch * SP;                          // zero pad rows on both sides
+        al = em + (size_t)(T + kPrefetch) * SP;
+        be = al + (size_t)T * SP;
+        dummy = reinterpret_cast<float *>(be + (size_t)T * SP);   // [0..1] write-only spare cell
+        cnt = reinterpret_cast<int *>(dummy + 8);
+        lab = cnt + 16;
+        occ = lab + ((SP + 3) & ~3);                        // [SP] occurrence index, [SPpad] their maximum
+        stage = reinterpret_cast<float *>(occ + ((SP + 3) & ~3) + 4);   // [workers][4 rows][RP]
+    }
+};
+
+static size_t r16_smem_bytes(int T, int SP, int C)
+{
+    const int RP = 32 * ((C + 31) / 32);
+    return (size_t)(3 * T + 2 * kPrefetch) * SP * 8 + (8 + 16 + 2 * ((SP + 3) & ~3) + 4) * 4 + (size_t)kPipeWorkers * 4 * RP * 4;
+}
+
+template <int CH2>
+__global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams p)
+{
+    extern __shared__ float4 smem_raw[];
+    constexpr int RP = 32 * CH2;                             // floats per staged row
+    constexpr int G = kPipeRows / 4;                         // groups of four rows per worker
+    const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, RP);
+    const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int u = (w == 0 || w == kChainB) ? -1 : (w < kChainB ? w - 1 : w - 2);
+    const int rho = lane >> 4, i16 = lane & 15;              // row of the group, position inside the row
+    const float ninf = -__builtin_inff();
+
+    if (p.stop == 1) return;                                 // diagnostic: cost of the bare dispatch
+    stamp(p, 0);
+    auto spread = [&](int which) {                           // diagnostic (stop == -50): entry / exit times of
+        if (p.stop != -50 || w != 1 || lane != 0) return;    // the first, middle and last workgroup, wave 1
+        const int bid = blockIdx.x, nb = gridDim.x;
+        const int slot = bid == 0 ? 0 : bid == nb / 2 ? 2 : bid == nb - 1 ? 4 : -1;
+        if (slot < 0) return;
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * (slot + which);
+        o[0] = __builtin_amdgcn_s_memtime();
+        o[1] = __builtin_amdgcn_s_memrealtime();
+    };
+    spread(0);
+    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
+    const int raw_label = tid < p.S ? load_label(p.lab, p.lab64, (int64_t)b * p.S + tid) : 0;
+    // this lane's row in each group, its columns: pairs (32j + 2i, 32j + 2i + 1)
+    int tv[G];
+    f2_t v[G][CH2];
+    const int c_lane = 2 * i16;
+    const bool col_ok = 32 * (CH2 - 1) + c_lane < p.C;       // last pair inside the row (C is even)
+    const int c_last = col_ok ? 32 * (CH2 - 1) + c_lane : p.C - 2;
+    if (u >= 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            tv[g] = pipe_row(p.T, u, 4 * g + rho);
+            const float *row = row_ptr(p, tv[g] >= 0 ? tv[g] : 0, b);
+#pragma unroll
+            for (int j = 0; j < CH2; ++j)
+                v[g][j] = *reinterpret_cast<const f2_t *>(row + (j < CH2 - 1 ? 32 * j + c_lane : c_last));
+        }
+    }
+    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
+    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
+
+    if (tid < p.SP) {
+        int k = 0;
+        if (tid < L) {
+            k = raw_label % p.C;
+            if (k < 0) k += p.C;                             // python negative index (NoBlankCTC.py:102)
+        }
+        sm.lab[tid] = k;
+    }
+    if (tid < 16) sm.cnt[tid] = 0;
+    const cell_t zero = make_cell(0.f, 0);
+    for (int i = tid; i < kPrefetch * p.SP; i += kThreads) {
+        sm.em[i - kPrefetch * p.SP] = zero;
+        sm.em[p.T * p.SP + i] = zero;
+    }
+    if (tid < 8) sm.dummy[tid] = 0.f;
+    __syncthreads();
+    stamp(p, 1);
+    if (p.stop == 2) return;                                 // diagnostic: dispatch + setup (+ loads in flight)
+
+    // ---------------------------------------------------------------- chain waves
+    if (u < 0) {
+        if (Tb > 0) {
+            cell_t *spare = reinterpret_cast<cell_t *>(sm.dummy + 2);
+            if (w == 0) {
+                // while the first rows are on their way: occurrence index of every state among equal
+                // labels (0 = first).  Repeated labels add up in the workers' occupancy tiles, one
+                // plain read-modify-write pass per repetition (P3); the table is ordered before the
+                // chain's first progress count, which every worker awaits before it reads it.
+                if (p.grad) {
+                    const int kl = lane < p.SP ? sm.lab[lane] : -1;
+                    int oc = 0;
+                    for (int l2 = 0; l2 < L; ++l2) {
+                        const int q = __builtin_amdgcn_readlane(kl, l2);
+                        oc += (l2 < lane && q == kl) ? 1 : 0;
+                    }
+                    if (lane >= L) oc = 0;
+                    int mo = 0;
+                    while (__builtin_amdgcn_ballot_w64(oc > mo) != 0) ++mo;
+                    if (lane < p.SP) sm.occ[lane] = oc;
+                    sm.occ[(p.SP + 3) & ~3] = mo;
+                    lds_order();
+                }
+                const cell_t a = xr_chain_sync<true>(p, sm.em, sm.al, spare, sm.cnt, p.T, Tb, L, p.SP);
+                stamp(p, 11);
+                const float ax = a.x;
+                const float am = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ax), L - 1));
+                const int ak = __builtin_amdgcn_readlane(cell_k(a), L - 1);
+                const float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(ak - kXrBias)) * kLn2 : -kNeg;
+                publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
+                                   [](float x, int) { return x; });
+            } else if (p.grad) {
+                xr_chain_sync<false>(p, sm.em, sm.be, spare, sm.cnt, p.T, Tb, L, p.SP);
+                stamp(p, 11);
+            }
+        } else if (w == 0) {
+            publish_and_reduce(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
+                               [](float x, int) { return x; });
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- workers
+    float *tile = sm.stage + (size_t)u * 4 * RP;             // this worker's staging / occupancy tile
+    float *tile_row = tile + rho * RP + c_lane;              // this lane's pair j lives at tile_row + 32 j
+    // states served by this lane in the two passes: l = i16 and l = 16 + i16 (S <= 31)
+    int lst[2];
+    float *gat[2];                                           // tile address of class lab[l] in this lane's row
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        lst[s] = 16 * s + i16;
+        gat[s] = tile + rho * RP + (lst[s] < p.SP ? sm.lab[lst[s]] : 0);
+    }
+    const bool own[2] = {lst[0] < L, lst[1] < L};
+    const float maskv = col_ok ? 0.f : ninf;
+    cell_t *const spare_w = reinterpret_cast<cell_t *>(sm.dummy);
+    float rs[G];                                             // grad_scale / sum_c exp(x - max), 0 for dead rows
+#pragma unroll
+    for (int g = 0; g < G; ++g) {                            // P1: extremes first
+        f2_t *x = v[g];
+        const int t = tv[g];
+        const bool live = t >= 0 && t < Tb;
+        float m = fmaxf(x[CH2 - 1].x, x[CH2 - 1].y) + maskv;
+#pragma unroll
+        for (int j = 0; j < CH2 - 1; ++j) m = fmaxf(m, fmaxf(x[j].x, x[j].y));
+        row16_allmax(m);
+        // raw rows -> tile, labels' logits back
+#pragma unroll
+        for (int j = 0; j < CH2; ++j) *reinterpret_cast<f2_t *>(tile_row + 32 * j) = x[j];
+        lds_order();
+        float xv[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) xv[s] = *gat[s];
+        lds_order();
+        // the row registers become exp(x - max): P3 needs softmax(x) = that times 1/sum
+        const float mb = -m * kLog2e;
+        x[CH2 - 1].x = __builtin_amdgcn_exp2f(__builtin_fmaf(x[CH2 - 1].x + maskv, kLog2e, mb));
+        x[CH2 - 1].y = __builtin_amdgcn_exp2f(__builtin_fmaf(x[CH2 - 1].y + maskv, kLog2e, mb));
+        float sum = x[CH2 - 1].x + x[CH2 - 1].y;
+#pragma unroll
+        for (int j = 0; j < CH2 - 1; ++j) {
+            x[j].x = __builtin_amdgcn_exp2f(__builtin_fmaf(x[j].x, kLog2e, mb));
+            x[j].y = __builtin_amdgcn_exp2f(__builtin_fmaf(x[j].y, kLog2e, mb));
+            sum += x[j].x + x[j].y;
+        }
+        row16_allsum(sum);
+        const float l2sum = __builtin_amdgcn_logf(sum);
+        rs[g] = live ? p.grad_scale * __builtin_amdgcn_rcpf(sum) : 0.f;
+        // emissions e = log_softmax(x)[lab_l] in log2 units, split into 2^floor * 2^frac
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float e2 = fmaxf(__builtin_fmaf(xv[s] - m, kLog2e, -l2sum), kXrMinLog2);
+            const float fl = __builtin_floorf(e2);
+            const float pm = __builtin_amdgcn_exp2f(e2 - fl);
+            cell_t *dst = (live && lst[s] < p.SP) ? sm.em + t * p.SP + lst[s] : spare_w;
+            *dst = lst[s] < L ? make_cell(pm, (int)fl) : zero;
+        }
+        lds_order();
+        sm.cnt[u] = 4 * (g + 1);                             // publishes the four slots (same wave: in order)
+    }
+    stamp(p, 2);
+    if (!p.grad) return;
+
+    const int Tlive = Tb;
+    const float gsc = p.grad_scale;
+    const cell_t *const zero_r = sm.em - kPrefetch * p.SP;   // a pad cell that stays zero
+    typedef const volatile __attribute__((address_space(3))) int lds_cvint;
+    const f2_t zero2 = {0.f, 0.f};
+
+    // P3: middle-out, one look at the chains' progress per group
+#pragma unroll
+    for (int g = G - 1; g >= 0; --g) {
+        int need_a = 0, need_b = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tk = pipe_row(p.T, u, 4 * g + k);      // scalar twin of tv[g]
+            if (tk >= 0 && tk < Tlive) {
+                need_a = max(need_a, tk + 1);
+                need_b = max(need_b, Tlive - tk);
+            }
+        }
+        if (need_a > 0) {
+            int spins = 0;
+            while ((*(lds_cvint *)(sm.cnt + kPipeWorkers) < need_a || *(lds_cvint *)(sm.cnt + kPipeWorkers + 1) < need_b) &&
+                   ++spins < kSpinLimit)
+                __builtin_amdgcn_s_sleep(8);
+            lds_order();
+        }
+        if (p.stop < 0) stamp(p, 3 + (G - 1 - g));
+        int occn[2] = {0, 0}, max_occ = 0;
+        if (need_a > 0) {                                    // (wave-uniform; a group without live rows adds nothing)
+            occn[0] = own[0] ? sm.occ[lst[0]] : 0;
+            occn[1] = own[1] ? sm.occ[lst[1]] : 0;
+            max_occ = __builtin_amdgcn_readfirstlane(sm.occ[(p.SP + 3) & ~3]);
+        }
+        f2_t *x = v[g];
+        const int t = tv[g];
+        const bool live = t >= 0 && t < Tlive;
+        // gamma_t(l) = alpha_t(l) beta_t(l) / sum_l' (...): mantissa products, exponents added and
+        // shifted by the row's largest
+        float pr[2];
+        int ks[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bool in = live && lst[s] < p.SP;
+            const int off = t * p.SP + lst[s];
+            const cell_t a = *(in ? sm.al + off : zero_r), bb = *(in ? sm.be + off : zero_r);
+            pr[s] = a.x * bb.x;
+            ks[s] = cell_k(a) + cell_k(bb);
+        }
+        int km = max(pr[0] > 0.f ? ks[0] : 0, pr[1] > 0.f ? ks[1] : 0);
+        row16_allmax(km);
+        float z[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) z[s] = __builtin_amdgcn_ldexpf(pr[s], ks[s] - km);
+        float tot = z[0] + z[1];
+        row16_allsum(tot);
+        const float rinv = (live && tot > 0.f) ? gsc * __builtin_amdgcn_rcpf(tot) : 0.f;
+        // class occupancy of the four rows: zero the tile, scatter-add the scaled posteriors
+#pragma unroll
+        for (int j = 0; j < CH2; ++j) *reinterpret_cast<f2_t *>(tile_row + 32 * j) = zero2;
+        lds_order();
+        // (only lanes that own a state write; pass k adds the k-th repetition of a label)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (own[s] && occn[s] == 0) *gat[s] = z[s] * rinv;
+        for (int k = 1; k <= max_occ; ++k) {
+            lds_order();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (own[s] && occn[s] == k) *gat[s] += z[s] * rinv;
+        }
+        lds_order();
+        // dense rows: grad = softmax(x) * scale - occupancy   (dead rows: scale = occupancy = 0)
+        if (t >= 0) {
+            float *gp = p.grad + ((int64_t)t * p.B + b) * p.C + c_lane;
+#pragma unroll
+            for (int j = 0; j < CH2; ++j) {
+                const f2_t occ = *reinterpret_cast<const f2_t *>(tile_row + 32 * j);
+                f2_t gv;
+                gv.x = __builtin_fmaf(x[j].x, rs[g], -occ.x);
+                gv.y = __builtin_fmaf(x[j].y, rs[g], -occ.y);
+#ifdef CTC_R16_NOSTORE
+                if (gv.x == 12345.f)
+#endif
+                if (j < CH2 - 1 || col_ok) __builtin_nontemporal_store(gv, reinterpret_cast<f2_t *>(gp + 32 * j));
+            }
+        }
+        lds_order();
+    }
+    stamp(p, 7);
+    spread(1);
+}
+
+}  // namespace ctc

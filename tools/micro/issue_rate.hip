@@ -1,0 +1,108 @@
+// Microbenchmark (diagnostic, not part of the product): single-wave issue cadence of the
+// instruction kinds the lattice chains are made of, on gfx950.  One wave, 256 repetitions of
+// each pattern between two s_memtime reads; prints shader-clock cycles per instruction.
+//   hipcc --offload-arch=gfx950 -O2 tools/micro/issue_rate.hip -o gpurun_out/issue_rate && gpurun_out/issue_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP4(x) x x x x
+#define REP16(x) REP4(REP4(x))
+#define REP64(x) REP4(REP16(x))
+
+#define BENCH(NAME, NINSTR, BODY)                                                          \
+    __global__ void NAME(unsigned long long *out, float *sink, float *lds_dummy)         \
+    {                                                                                      \
+        __shared__ float lds[4096];                                                        \
+        ((int *)lds)[threadIdx.x] = (threadIdx.x * 4) % 256; lds[threadIdx.x + 64] = 1.f;                      \
+        float v0 = threadIdx.x, v1 = 1.0001f, v2 = 3.f, v3 = 4.f, v4 = 5.f, v5 = 6.f, v6 = 7.f, v7 = 8.f; \
+        int i0 = threadIdx.x, i1 = 3, i2 = 5, i3 = 1;                                      \
+        int addr = (threadIdx.x * 4) % 256;                                                        \
+        __syncthreads();                                                                   \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+        for (int it = 0; it < 4; ++it) {                                                   \
+            asm volatile(REP64(BODY)                                                       \
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), \
+                           "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(addr)              \
+                         :: "memory", "v20", "v21", "v22", "v23", "s20");                  \
+        }                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");                        \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                             \
+        if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = 256ull * NINSTR; }              \
+        sink[threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + i0 + i1 + i2 + i3 + addr; \
+    }
+
+// operands: %0..%7 floats v0..v7, %8..%11 ints, %12 addr
+BENCH(dep_add, 1, "v_add_f32 %0, %0, %1\n\t")
+BENCH(indep_add, 4, "v_add_f32 %0, %0, %1\n\tv_add_f32 %2, %2, %1\n\tv_add_f32 %3, %3, %1\n\tv_add_f32 %4, %4, %1\n\t")
+BENCH(dep_mul, 1, "v_mul_f32 %0, %0, %1\n\t")
+BENCH(dep_ldexp, 1, "v_ldexp_f32 %0, %0, %9\n\t")
+BENCH(indep_ldexp, 4, "v_ldexp_f32 %0, %0, %9\n\tv_ldexp_f32 %2, %2, %9\n\tv_ldexp_f32 %3, %3, %9\n\tv_ldexp_f32 %4, %4, %9\n\t")
+BENCH(dep_maxi, 1, "v_max_i32 %8, %8, %9\n\t")
+BENCH(dep_maxi_dpp, 1, "v_max_i32_dpp %8, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t")
+BENCH(dep_mov_dpp, 1, "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t")
+BENCH(dep_mov_dpp_rowshr, 1, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t")
+BENCH(dep_add_dpp_rowshr, 1, "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t")
+BENCH(dep_add_dpp_waveshr, 1, "v_add_f32_dpp %0, %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t")
+BENCH(dep_exp, 1, "v_exp_f32 %0, %0\n\t")
+BENCH(indep_exp, 4, "v_exp_f32 %0, %1\n\tv_exp_f32 %2, %1\n\tv_exp_f32 %3, %1\n\tv_exp_f32 %4, %1\n\t")
+BENCH(dep_log, 1, "v_log_f32 %0, %0\n\t")
+BENCH(dep_frexp, 2, "v_frexp_exp_i32_f32 %8, %0\n\tv_frexp_mant_f32 %0, %0\n\t")
+BENCH(dep_fma, 1, "v_fma_f32 %0, %0, %1, %2\n\t")
+BENCH(dep_cndmask, 1, "v_cndmask_b32 %0, %0, %1, vcc\n\t")
+BENCH(lds_read_dep, 1, "ds_read_b32 %12, %12\n\ts_waitcnt lgkmcnt(0)\n\t")
+BENCH(lds_rw_indep, 2, "ds_read_b64 v[20:21], %12\n\tds_write_b64 %12, v[22:23] offset:2048\n\t")
+BENCH(salu_dep, 1, "s_add_u32 s20, s20, 1\n\t")
+BENCH(salu_valu_mix, 2, "s_add_u32 s20, s20, 1\n\tv_add_f32 %0, %0, %1\n\t")
+// the extended-range chain step as compiled (11 VALU), no LDS
+BENCH(xr_step, 11,
+      "v_max_i32_dpp %10, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_sub_u32 %11, %8, %10\n\t"
+      "v_sub_u32_dpp %8, %8, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %0, %0, %11\n\t"
+      "v_ldexp_f32 %3, %2, %8\n\t"
+      "v_add_f32 %0, %0, %3\n\t"
+      "v_add_u32 %12, %12, %9\n\t"
+      "v_mul_f32 %0, %1, %0\n\t"
+      "v_add_u32 %8, %10, %9\n\t"
+      "v_add_u32 %12, %12, %9\n\t")
+// the log-domain step (8 dependent ops incl. exp/log)
+BENCH(log_step, 8,
+      "v_mov_b32_dpp %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_sub_f32 %3, %0, %2\n\t"
+      "v_mul_f32 %3, |%3|, %1\n\t"
+      "v_exp_f32 %3, %3\n\t"
+      "v_max_f32 %4, %0, %2\n\t"
+      "v_add_f32 %3, 1.0, %3\n\t"
+      "v_log_f32 %3, %3\n\t"
+      "v_fma_f32 %0, %3, %1, %4\n\t")
+// the common-scale linear step
+BENCH(lin_step, 2,
+      "v_add_f32_dpp %0, %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mul_f32 %0, %0, %1\n\t")
+
+typedef void (*kern_t)(unsigned long long *, float *, float *);
+struct Entry { const char *name; kern_t k; };
+#define E(n) {#n, n}
+
+int main()
+{
+    unsigned long long *out;
+    float *sink;
+    if (hipMalloc(&out, 64) != hipSuccess || hipMalloc(&sink, 4096) != hipSuccess) return 1;
+    std::vector<Entry> es = {E(dep_add), E(indep_add), E(dep_mul), E(dep_ldexp), E(indep_ldexp), E(dep_maxi), E(dep_maxi_dpp),
+                             E(dep_mov_dpp), E(dep_mov_dpp_rowshr), E(dep_add_dpp_rowshr), E(dep_add_dpp_waveshr), E(dep_exp),
+                             E(indep_exp), E(dep_log), E(dep_frexp), E(dep_fma), E(dep_cndmask), E(lds_read_dep), E(lds_rw_indep),
+                             E(salu_dep), E(salu_valu_mix), E(xr_step), E(log_step), E(lin_step)};
+    for (auto &e : es) {
+        unsigned long long h[2] = {0, 0};
+        for (int r = 0; r < 3; ++r) {
+            hipLaunchKernelGGL(e.k, dim3(1), dim3(64), 0, 0, out, sink, sink);
+            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, out, 16, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+        }
+        printf("%-22s %8llu cycles / %5llu instr = %6.2f cycles per instr\n", e.name, h[0], h[1], (double)h[0] / h[1]);
+    }
+    return 0;
+}

@@ -25,9 +25,14 @@ torch.cuda.synchronize()
 ws[64:].zero_()
 wl.fused(loss.data_ptr(), ws, s)
 torch.cuda.synchronize()
-st = ws.cpu().numpy()[64:64 + 8 * 16].view(np.uint64).reshape(8, 2).astype(np.int64)
+st = ws.cpu().numpy()[64:64 + 12 * 16].view(np.uint64).reshape(12, 2).astype(np.int64)
+if os.environ.get("CTC_AMD_DEBUG_STOP") == "-50":
+    names = ["first wg entry", "first wg exit", "middle wg entry", "middle wg exit", "last wg entry", "last wg exit"]
+    for i in range(6):
+        print("  %-16s %7.2f us (realtime, relative to the first workgroup's entry)" % (names[i], (st[i][1] - st[0][1]) / 100.0))
+    sys.exit(0)
 print("slot: us since entry (slots mean different things per kernel/wave, see the kernel source)")
-for i in range(8):
+for i in range(12):
     if st[i][1] > 0:
         print("  slot %d: %7.2f us  %8d cyc" % (i, (st[i][1] - st[0][1]) / 100.0, st[i][0] - st[0][0]))
 
