@@ -205,7 +205,7 @@ template <typename P>
 __device__ __forceinline__ void stamp(const P &p, int slot)
 {
     if (p.stop >= 0) return;
-    if (blockIdx.x == 0 && wave_id() == -p.stop - 1 && lane_id() == 0) {
+    if (blockIdx.x == 0 && wave_id() == (p.stop <= -60 ? -60 - p.stop : -p.stop - 1) && lane_id() == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
         o[0] = __builtin_amdgcn_s_memtime();
         o[1] = __builtin_amdgcn_s_memrealtime();
@@ -216,15 +216,18 @@ __device__ __forceinline__ void stamp(const P &p, int slot)
 // arrival ticket).  Caller: exactly one wave per workgroup, after lane 0 has the
 // sample's value.  nll is stored write-through (sc1), drained, then the ticket is
 // drawn; the workgroup drawing B-1 reads every nll with sc1 loads in a fixed order.
+// (two halves, so that a caller can start the write-through store early and draw the ticket later)
+__device__ __forceinline__ void publish_value(float value, int b, float *nll)
+{
+    if (lane_id() == 0) __hip_atomic_store(&nll[b], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <typename F>
-__device__ __forceinline__ void publish_and_reduce(float value, int b, int B, float *nll,
-                                                   float *loss, float loss_scale,
-                                                   unsigned *counter, F per_sample)
+__device__ __forceinline__ void ticket_and_reduce(int B, float *nll, float *loss, float loss_scale, unsigned *counter,
+                                                  F per_sample)
 {
     int last = 0;
     if (lane_id() == 0) {
-        __hip_atomic_store(&nll[b], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's nll store has reached L2
         unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = (ticket == (unsigned)(B - 1));
     }
@@ -238,6 +241,14 @@ __device__ __forceinline__ void publish_and_reduce(float value, int b, int B, fl
         loss[0] = s * loss_scale;
         __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+template <typename F>
+__device__ __forceinline__ void publish_and_reduce(float value, int b, int B, float *nll,
+                                                   float *loss, float loss_scale,
+                                                   unsigned *counter, F per_sample)
+{
+    publish_value(value, b, nll);
+    ticket_and_reduce(B, nll, loss, loss_scale, counter, per_sample);
 }
 
 }  // namespace ctc

@@ -13,11 +13,13 @@
 #define BENCH(NAME, NINSTR, BODY)                                                          \
     __global__ void NAME(unsigned long long *out, float *sink, float *lds_dummy)         \
     {                                                                                      \
-        __shared__ float lds[4096];                                                        \
-        ((int *)lds)[threadIdx.x] = (threadIdx.x * 4) % 256; lds[threadIdx.x + 64] = 1.f;                      \
+        extern __shared__ float lds_dyn[];                                                 \
+        float *lds = lds_dyn + out[3] / 4;                  /* byte offset of the working set */ \
+        if (out[2] != 0 && threadIdx.x >= 64) return;      /* solo mode: the other waves leave */ \
+        ((int *)lds)[threadIdx.x & 63] = (threadIdx.x * 4) % 256; lds[(threadIdx.x & 63) + 64] = 1.f;                      \
         float v0 = threadIdx.x, v1 = 1.0001f, v2 = 3.f, v3 = 4.f, v4 = 5.f, v5 = 6.f, v6 = 7.f, v7 = 8.f; \
-        int i0 = threadIdx.x, i1 = 3, i2 = 5, i3 = 1;                                      \
-        int addr = (threadIdx.x * 4) % 256;                                                        \
+        int i0 = threadIdx.x, i1 = 3, i2 = 5, i3 = (threadIdx.x & 63) < 20 ? (threadIdx.x & 63) * 8 : 1024;                                      \
+        int addr = (threadIdx.x & 63) * 8 + (int)out[3];                                                        \
         __syncthreads();                                                                   \
         unsigned long long t0 = __builtin_amdgcn_s_memtime();                             \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
@@ -25,12 +27,12 @@
             asm volatile(REP64(BODY)                                                       \
                          : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), \
                            "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(addr)              \
-                         :: "memory", "v20", "v21", "v22", "v23", "s20");                  \
+                         :: "memory", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "s20");                  \
         }                                                                                  \
         asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");                        \
         unsigned long long t1 = __builtin_amdgcn_s_memtime();                             \
-        if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = 256ull * NINSTR; }              \
-        sink[threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + i0 + i1 + i2 + i3 + addr; \
+        if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = 256ull * NINSTR; }              \
+        sink[threadIdx.x & 63] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + i0 + i1 + i2 + i3 + addr; \
     }
 
 // operands: %0..%7 floats v0..v7, %8..%11 ints, %12 addr
@@ -83,9 +85,71 @@ BENCH(lin_step, 2,
       "v_add_f32_dpp %0, %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_mul_f32 %0, %0, %1\n\t")
 
+// the fast-pass (double, common scale) chain step: product, two DPP moves, fma
+BENCH(f64_step, 4,
+      "v_mul_f64 v[20:21], v[22:23], v[20:21]\n\t"
+      "v_mov_b32_dpp %2, v21 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %3, v20 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fma_f64 v[20:21], v[22:23], v[20:21], v[20:21]\n\t")
+BENCH(dep_mul_f64, 1, "v_mul_f64 v[20:21], v[22:23], v[20:21]\n\t")
+BENCH(dep_fma_f64, 1, "v_fma_f64 v[20:21], v[22:23], v[20:21], v[20:21]\n\t")
+// the same with its LDS traffic: one 8-byte read, one 8-byte write, two address bumps
+BENCH(f64_step_lds, 8,
+      "v_mul_f64 v[20:21], v[22:23], v[20:21]\n\t"
+      "ds_read_b64 v[22:23], %12\n\t"
+      "v_add_u32 %12, %12, %9\n\t"
+      "v_mov_b32_dpp %2, v21 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %3, v20 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fma_f64 v[20:21], v[22:23], v[20:21], v[20:21]\n\t"
+      "ds_write_b64 %12, v[20:21] offset:2048\n\t"
+      "s_waitcnt lgkmcnt(1)\n\t")
+BENCH(lds_rw_b32, 2, "ds_read_b32 v20, %12\n\tds_write_b32 %12, v22 offset:2048\n\t")
+BENCH(lds_rw_b128, 2, "ds_read_b128 v[20:23], %12\n\tds_write_b128 %12, v[20:23] offset:2048\n\t")
+
+// chain-like LDS traffic: 20 lanes with their own cells, 44 idle lanes all on ONE spare address
+BENCH(lds_w_idle_same, 1, "ds_write_b64 %11, v[22:23] offset:2048\n\t")
+BENCH(lds_r_idle_same, 1, "ds_read_b64 v[20:21], %11\n\t")
+BENCH(lds_w_distinct, 1, "ds_write_b64 %12, v[22:23] offset:2048\n\t")
+BENCH(lds_r_distinct, 1, "ds_read_b64 v[20:21], %12\n\t")
+
+// the fast chain's step exactly as compiled (two steps, state ping-pong), with and without LDS
+BENCH(f64_chain_real, 14,
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_mul_f64 v[20:21], v[26:27], v[24:25]\n\t"
+      "ds_write_b64 %12, v[20:21] offset:2048\n\t"
+      "ds_read_b64 v[28:29], %12 offset:8\n\t"
+      "v_mov_b32_dpp v21, v21 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp v20, v20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fma_f64 v[20:21], v[26:27], v[24:25], v[20:21]\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_mul_f64 v[24:25], v[28:29], v[20:21]\n\t"
+      "ds_write_b64 %12, v[24:25] offset:2056\n\t"
+      "ds_read_b64 v[26:27], %12 offset:16\n\t"
+      "v_mov_b32_dpp v25, v25 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp v24, v24 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fma_f64 v[24:25], v[28:29], v[20:21], v[24:25]\n\t"
+)
+BENCH(f64_chain_nowait, 12,
+      "v_mul_f64 v[20:21], v[26:27], v[24:25]\n\t"
+      "ds_write_b64 %12, v[20:21] offset:2048\n\t"
+      "ds_read_b64 v[28:29], %12 offset:8\n\t"
+      "v_mov_b32_dpp v21, v21 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp v20, v20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fma_f64 v[20:21], v[26:27], v[24:25], v[20:21]\n\t"
+      "v_mul_f64 v[24:25], v[28:29], v[20:21]\n\t"
+      "ds_write_b64 %12, v[24:25] offset:2056\n\t"
+      "ds_read_b64 v[26:27], %12 offset:16\n\t"
+      "v_mov_b32_dpp v25, v25 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp v24, v24 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fma_f64 v[24:25], v[28:29], v[20:21], v[24:25]\n\t"
+)
+
 typedef void (*kern_t)(unsigned long long *, float *, float *);
-struct Entry { const char *name; kern_t k; };
-#define E(n) {#n, n}
+struct Entry { const char *name; kern_t k; int waves; int grid; int solo; int ldsb; int off; };
+#define E(n) {#n, n, 1, 1, 0, 16384, 0}
+#define EW(n, w) {#n " x" #w " waves", n, w, 1, 0, 16384, 0}
+#define EG(n, w, g, so) {#n " " #w "w grid" #g " solo" #so, n, w, g, so, 16384, 0}
+#define EL(n, ldsb, off) {#n " lds" #ldsb " off" #off, n, 1, 1, 0, ldsb, off}
 
 int main()
 {
@@ -95,14 +159,25 @@ int main()
     std::vector<Entry> es = {E(dep_add), E(indep_add), E(dep_mul), E(dep_ldexp), E(indep_ldexp), E(dep_maxi), E(dep_maxi_dpp),
                              E(dep_mov_dpp), E(dep_mov_dpp_rowshr), E(dep_add_dpp_rowshr), E(dep_add_dpp_waveshr), E(dep_exp),
                              E(indep_exp), E(dep_log), E(dep_frexp), E(dep_fma), E(dep_cndmask), E(lds_read_dep), E(lds_rw_indep),
-                             E(salu_dep), E(salu_valu_mix), E(xr_step), E(log_step), E(lin_step)};
+                             E(salu_dep), E(salu_valu_mix), E(xr_step), E(log_step), E(lin_step), E(f64_step), E(dep_mul_f64), E(dep_fma_f64),
+                             E(f64_step_lds), E(lds_rw_b32), E(lds_rw_b128), E(lds_w_idle_same), E(lds_r_idle_same),
+                             E(lds_w_distinct), E(lds_r_distinct), EW(lds_w_distinct, 2), EW(lds_w_distinct, 4),
+                             EW(lds_r_distinct, 2), EW(lds_rw_indep, 2), EW(lds_rw_indep, 4), EW(lds_rw_indep, 16), EW(dep_add, 2), EW(dep_add, 8),
+                             EW(f64_step, 2), EW(lds_rw_b32, 2), EW(lds_rw_b32, 4), E(f64_chain_real), E(f64_chain_nowait),
+                             EW(f64_chain_real, 2), EW(f64_chain_real, 16), EG(f64_chain_real, 1, 256, 0), EG(f64_chain_real, 16, 1, 1),
+                             EG(f64_chain_real, 16, 256, 1), EG(f64_chain_real, 2, 256, 0), EG(dep_add, 1, 256, 0), EG(dep_add, 16, 256, 1), EG(f64_step, 16, 256, 1),
+                             EL(f64_chain_real, 143360, 0), EL(f64_chain_real, 143360, 65536), EL(f64_chain_real, 143360, 131072),
+                             EL(lds_r_distinct, 143360, 0), EL(lds_r_distinct, 143360, 131072), EL(lds_w_distinct, 143360, 131072), EL(lds_read_dep, 143360, 0)};
     for (auto &e : es) {
         unsigned long long h[2] = {0, 0};
         for (int r = 0; r < 3; ++r) {
-            hipLaunchKernelGGL(e.k, dim3(1), dim3(64), 0, 0, out, sink, sink);
+            unsigned long long cfg[2] = {(unsigned long long)e.solo, (unsigned long long)e.off};
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 4;
+            if (hipMemcpy(out + 2, cfg, 16, hipMemcpyHostToDevice) != hipSuccess) return 3;
+            hipLaunchKernelGGL(e.k, dim3(e.grid), dim3(64 * e.waves), e.ldsb, 0, out, sink, sink);
             if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, out, 16, hipMemcpyDeviceToHost) != hipSuccess) return 2;
         }
-        printf("%-22s %8llu cycles / %5llu instr = %6.2f cycles per instr\n", e.name, h[0], h[1], (double)h[0] / h[1]);
+        printf("%-30s %8llu cycles / %5llu instr = %6.2f cycles per instr\n", e.name, h[0], h[1], (double)h[0] / h[1]);
     }
     return 0;
 }
