@@ -205,7 +205,7 @@ template <typename P>
 __device__ __forceinline__ void stamp(const P &p, int slot)
 {
     if (p.stop >= 0) return;
-    if (blockIdx.x == 0 && wave_id() == (p.stop <= -60 ? -60 - p.stop : -p.stop - 1) && lane_id() == 0) {
+    if (blockIdx.x == 0 && wave_id() == -p.stop - 1 && lane_id() == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
         o[0] = __builtin_amdgcn_s_memtime();
         o[1] = __builtin_amdgcn_s_memrealtime();

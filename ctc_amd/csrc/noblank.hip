@@ -43,7 +43,6 @@ struct NoblankParams {
     float *lattice;             // global-memory lattice slabs (workspace + 256 B) when T x S exceeds LDS
     int64_t slab;               // floats per sample in `lattice`
     unsigned *counter;
-    int r16_mode;               // noblank_r16.hpp, diagnostics: 1 = robust pass only, 2 = distrust the fast pass
 };
 
 #ifndef CTC_NOBLANK_THREADS
@@ -441,10 +440,10 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     p.SP = (S + K - 1) / K * K;
     static const int debug_stop = getenv("CTC_AMD_DEBUG_STOP") ? atoi(getenv("CTC_AMD_DEBUG_STOP")) : 0;
     p.stop = debug_stop;
-    static const int r16_mode = getenv("CTC_AMD_R16_MODE") ? atoi(getenv("CTC_AMD_R16_MODE")) : 0;
-    p.r16_mode = r16_mode;
     p.loss_scale = loss_scale; p.grad_scale = grad_scale;
     p.nll = nll; p.loss = loss; p.grad = grad; p.gamma = nullptr;
+    static const bool debug_nograd = getenv("CTC_AMD_DEBUG_NOGRAD") != nullptr;   // diagnostic: forward only
+    if (debug_nograd) p.grad = nullptr;
     p.counter = static_cast<unsigned *>(workspace);
     p.lattice = nullptr; p.slab = 0;
     size_t smem = noblank_smem_bytes(T, p.SP, C);
@@ -558,7 +557,7 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
     p.in_len = in_len; p.tgt_len = tgt_len;
     p.T = T; p.B = B; p.C = C; p.S = S;
     p.SP = (S + K - 1) / K * K;
-    p.stop = 0; p.r16_mode = 0;
+    p.stop = 0;
     p.loss_scale = 0.f; p.grad_scale = 0.f;
     p.nll = nll; p.grad = nullptr; p.gamma = gamma;
     // the batch-mean slot of the in-launch reduction lands in a spare workspace word

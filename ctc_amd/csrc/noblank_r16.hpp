@@ -23,19 +23,11 @@
 // About 45 instructions per row instead of ~250.  Needs C even (8-byte aligned rows), C <= 256,
 // S <= 31, T <= 168 and 35 KB more LDS than noblank_xr.hpp (one workgroup per CU).
 //
-// With the workers this lean the two chain waves are the critical path, so the lattice is first
-// tried in plain DOUBLE precision with one common power-of-two scale per chain ("fast pass"):
-// a step is two DPP moves, one v_add_f64 and one v_mul_f64 (both full rate on gfx950) instead of
-// the eleven instructions of the per-state-exponent chain.  A common scale holds states that lie
-// within 2^+-1022 of each other; what falls below is flushed, and if flushed mass mattered the
-// answer would be wrong.  That is DETECTED, not assumed away: in exact arithmetic the row total
-// sum_l alpha_t(l) beta_t(l) is the same number P(x, labels) for every t, and a path set lost by
-// one chain at some step is missing from the rows on one side of that step only -- so every
-// worker tracks the smallest and largest log2 row total it sees, and unless all live rows agree
-// to 1e-4 (and no emission or row total underflowed) the workgroup repeats the sample with the
-// extended-range lattice of noblank_xr.hpp ("robust pass", any contrast, ~2x slower).  Emissions
-// are normalised per row (largest label probability = 1) so that only state CONTRAST, never the
-// overall level of the probabilities, eats into the range.
+// Measured and NOT kept (git history): a first pass in plain doubles under one common
+// scale per chain (4 instead of 11 VALU instructions per step) with a row-total self-check and this
+// lattice as the fallback -- the chain is bound by its two LDS operations and its per-block
+// bookkeeping, not by its arithmetic (89 against 100 cycles per step), and the check's barrier and
+// the later loss ticket cost more than the chain gained (19.2 against 17.4 us at config 2).
 #pragma once
 
 namespace ctc {
@@ -71,11 +63,9 @@ __host__ __device__ inline int r16_pitch(int T)
 
 struct R16Smem {
     int TP;
-    cell_t *em, *al, *be;                                    // robust pass: (mantissa, exponent) cells
-    double *emd, *ald, *bed;                                 // fast pass: the same storage as doubles
-    float *dummy, *stage, *cs;
-    double *vmin, *vmax;
-    int *cnt, *lab, *occ, *ka, *kb;
+    cell_t *em, *al, *be;                                    // (mantissa, exponent) cells, [state][time]
+    float *dummy, *stage;
+    int *cnt, *lab, *occ;
     __device__ R16Smem(float *base, int T, int SP, int RP)
     {
         TP = r16_pitch(T);
@@ -83,70 +73,44 @@ struct R16Smem {
         em = lat + kR16Pad;                                  // -> cell (t = 0, l = 0)
         al = em + (size_t)(SP + 1) * TP;
         be = al + (size_t)(SP + 1) * TP;
-        emd = reinterpret_cast<double *>(em);
-        ald = reinterpret_cast<double *>(al);
-        bed = reinterpret_cast<double *>(be);
-        vmin = reinterpret_cast<double *>(lat + (size_t)3 * (SP + 1) * TP);   // [4 * workers] extremes of log2 row totals
-        vmax = vmin + 4 * kPipeWorkers;
-        dummy = reinterpret_cast<float *>(vmax + 4 * kPipeWorkers);   // write-only spare cells
+        dummy = reinterpret_cast<float *>(lat + (size_t)3 * (SP + 1) * TP);   // write-only spare cells
         cnt = reinterpret_cast<int *>(dummy + 8);
         lab = cnt + 16;
         occ = lab + ((SP + 3) & ~3);                        // [SP] occurrence index, [SPpad] their maximum
-        ka = occ + ((SP + 3) & ~3) + 4;                     // [T] common exponent of the alpha / beta rows
-        kb = ka + ((T + 3) & ~3);
-        cs = reinterpret_cast<float *>(kb + ((T + 3) & ~3));     // [T] log2 of the row's largest label probability
-        stage = cs + ((T + 3) & ~3);                        // [workers][4 rows][RP]
+        stage = reinterpret_cast<float *>(occ + ((SP + 3) & ~3) + 4);   // [workers][4 rows][RP]
     }
 };
 
 static size_t r16_smem_bytes(int T, int SP, int C)
 {
     const int RP = 32 * ((C + 31) / 32);
-    return (size_t)3 * (SP + 1) * r16_pitch(T) * 8 + (size_t)8 * kPipeWorkers * 8 +
-           (8 + 16 + 2 * ((SP + 3) & ~3) + 4 + 3 * ((T + 3) & ~3)) * 4 + (size_t)kPipeWorkers * 4 * RP * 4;
+    return (size_t)3 * (SP + 1) * r16_pitch(T) * 8 + (8 + 16 + 2 * ((SP + 3) & ~3) + 4) * 4 +
+           (size_t)kPipeWorkers * 4 * RP * 4;
 }
 
-template <bool FWD>
-__device__ __forceinline__ double f64_nb(double a)
-{
-    return __hiloint2double(xr_nb<FWD>(__double2hiint(a)), xr_nb<FWD>(__double2loint(a)));
-}
-
-// alpha (FWD) / beta (!FWD) chain of this kernel, both arithmetics:
-//   FAST  : plain doubles under one common scale 2^K per chain, renewed once per block from the
-//           largest state; K of every row goes to ka / kb.  Step = 2 DPP moves + v_mul_f64 + v_fma_f64.
-//   !FAST : (mantissa, exponent) cells as in xr_chain_sync (noblank_xr.hpp), any contrast.
-// Conventions as there: alpha_t is stored with, beta_t without the emission of step t.
+// alpha (FWD) / beta (!FWD) chain of this kernel: (mantissa, exponent) cells as in xr_chain_sync
+// (noblank_xr.hpp), alpha_t stored with, beta_t without the emission of step t.
 // Hand-off: a worker publishes its rows in groups of four slots; group g of ALL workers together
 // covers positions [28 g, 28 g + 28) of each half of the sequence, so "rows up to position q are
 // there" is one scalar: the number of groups every worker must have finished.  It changes three
 // times per chain; a block of steps whose requirement is already met costs no look at all.
-template <bool FWD, bool FAST>
-__device__ __forceinline__ void r16_chain(const NoblankParams &p, const R16Smem &sm, int T, int Tb, int L, int SP,
-                                          double &afin, int &kfin, cell_t &cfin)
+// Returns alpha[T_b-1, L_b-1] (FWD) as a cell.
+template <bool FWD>
+__device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Smem &sm, int T, int Tb, int L, int SP)
 {
     constexpr int G = kPipeRows / 4;
     constexpr int D = FWD ? 1 : -1;
     const int lane = lane_id();
-    // lanes beyond the states (and beyond the 14 progress counters) sit the chain out: the LDS then
-    // serves 20-odd lanes per access instead of 64, and a DPP read from a disabled lane is the zero
-    // the first / last state needs anyway (bound_ctrl)
-    afin = 0.0;
-    kfin = 0;
-    cfin = make_cell(0.f, 0);
-    if (lane >= (SP > kPipeWorkers ? SP : kPipeWorkers)) return;
-    const int lrow = lane < SP ? lane : SP;                  // idle lanes: the spare state row
+    // lanes beyond the states (and beyond the 14 progress counters) sit the chain out: a DPP read
+    // from a disabled lane is the zero the first / last state needs anyway (bound_ctrl)
+    if (lane >= (SP > kPipeWorkers ? SP : kPipeWorkers)) return make_cell(0.f, 0);
+    const int lrow = lane < SP ? lane : SP;                  // counter-only lanes: the spare state row
     const int t_first = FWD ? 0 : Tb - 1;
     const cell_t *rd = sm.em + (size_t)lrow * sm.TP + t_first;
     cell_t *wr = (FWD ? sm.al : sm.be) + (size_t)lrow * sm.TP + t_first;
-    int *krow = FWD ? sm.ka : sm.kb;
-    double a = 0.0;                                          // FAST state
-    int K = 0;
-    float m = 0.f;                                           // !FAST state
-    int k = 0;
+    float m;
+    int k;
     cell_t ring[kPrefetch];
-    auto as_double = [](cell_t c) { return __builtin_bit_cast(double, c); };
-    auto as_cell = [](double d) { return __builtin_bit_cast(cell_t, d); };
 
     const int H = (T + 1) >> 1;
     const int pos0 = FWD ? 0 : T - Tb;                       // position (in this chain's half order) of step 0
@@ -166,17 +130,7 @@ __device__ __forceinline__ void r16_chain(const NoblankParams &p, const R16Smem 
         lds_order();
         have = ng;
     };
-    auto rescale = [&](int i) {                              // FAST, before step i: largest state back to [0.5, 1)
-        int hi = __double2hiint(a);                          // a >= 0: the high word orders like the value
-        row16_allmax(hi);
-        const int mx = max(__builtin_amdgcn_readlane(hi, 0), SP > 16 ? __builtin_amdgcn_readlane(hi, 16) : 0);   // SP <= 31
-        const int e = mx > 0 ? (mx >> 20) - 1022 : 0;
-        a = __builtin_ldexp(a, -e);
-        K += e;
-        const int row = FWD ? i + lane : Tb - 1 - i - lane;  // rows of the coming block
-        if (lane < kBlockSteps && row >= 0 && row < Tb) krow[row] = K;
-    };
-    auto merge = [&]() {                                     // !FAST: (m,k) += neighbour, in the larger exponent
+    auto merge = [&]() {                                     // (m,k) += neighbour, in the larger exponent
         const int nk = xr_nb<FWD>(k);
         const float nm = __builtin_bit_cast(float, xr_nb<FWD>(__builtin_bit_cast(int, m)));
         const int kk = k > nk ? k : nk;
@@ -184,56 +138,31 @@ __device__ __forceinline__ void r16_chain(const NoblankParams &p, const R16Smem 
         k = kk;
     };
     auto step = [&](cell_t ec, bool norm, cell_t *dst) {
-        if (FAST) {
-            const double e = as_double(ec);
-            if (FWD) {
-                a = (a + f64_nb<true>(a)) * e;
-            } else {
-                a *= e;
-                a += f64_nb<false>(a);
-            }
-#ifdef CTC_R16_EXP_NOWRITE
-            if (a == 12345.0)
-#endif
-            *dst = as_cell(a);
-        } else {
-            if (FWD) merge();
-            m *= ec.x;
-            k += cell_k(ec);
-            if (norm) {
-                k += __builtin_amdgcn_frexp_expf(m);
-                m = __builtin_amdgcn_frexp_mantf(m);
-            }
-            if (!FWD) merge();
-            *dst = make_cell(m, k);
+        if (FWD) merge();
+        m *= ec.x;
+        k += cell_k(ec);
+        if (norm) {                                          // mantissa back into [0.5, 1)
+            k += __builtin_amdgcn_frexp_expf(m);
+            m = __builtin_amdgcn_frexp_mantf(m);
         }
+        if (!FWD) merge();
+        *dst = make_cell(m, k);
     };
 
     int *prog = sm.cnt + kPipeWorkers + (FWD ? 0 : 1);
-#ifndef CTC_R16_NOPRIO
     __builtin_amdgcn_s_setprio(3);                           // the chains are the critical path
-#endif
     wait_upto(kPrefetch);
     if (FWD) {                                               // alpha_0 = p_0(0) on state 0 only
         const cell_t e0 = *rd;
         rd += D;
-        if (FAST) {
-            a = lane == 0 ? as_double(e0) : 0.0;
-        } else {
-            m = lane == 0 ? e0.x : 0.f;
-            k = lane == 0 ? kXrBias + cell_k(e0) : 0;
-        }
+        m = lane == 0 ? e0.x : 0.f;
+        k = lane == 0 ? kXrBias + cell_k(e0) : 0;
     } else {                                                 // beta_{T_b-1} = 1 on state L-1 only
-        if (FAST) {
-            a = lane == L - 1 ? 1.0 : 0.0;
-        } else {
-            m = lane == L - 1 ? 1.f : 0.f;
-            k = lane == L - 1 ? kXrBias : 0;
-        }
+        m = lane == L - 1 ? 1.f : 0.f;
+        k = lane == L - 1 ? kXrBias : 0;
     }
-    *wr = FAST ? as_cell(a) : make_cell(m, k);
+    *wr = make_cell(m, k);
     wr += D;
-    if (FAST && lane == 0) krow[t_first] = 0;
 #pragma unroll
     for (int j = 0; j < kPrefetch; ++j) ring[j] = rd[D * j];
     rd += D * kPrefetch;
@@ -247,25 +176,12 @@ __device__ __forceinline__ void r16_chain(const NoblankParams &p, const R16Smem 
         lds_order();
         *prog = i;                                           // steps < i are done (every lane, same value)
         wait_upto(i + kBlockSteps - 1 + kPrefetch);
-#ifdef CTC_R16_SPLIT_STAMPS
-        if (p.stop < 0 && i < 5 * kBlockSteps) stamp(p, 2 + 2 * (i / kBlockSteps));
-        if (FAST) rescale(i);
-        if (p.stop < 0 && i < 5 * kBlockSteps) stamp(p, 3 + 2 * (i / kBlockSteps));
-#else
         if (p.stop < 0) stamp(p, 2 + i / kBlockSteps);       // diagnostic: block starts -> slots 2..10
-        if (FAST) rescale(i);
-#endif
 #pragma unroll
         for (int j = 0; j < kBlockSteps; ++j) {
             const cell_t e = ring[j % kPrefetch];
-#ifndef CTC_R16_EXP_NOREAD
             ring[j % kPrefetch] = rb[FWD ? j : kLast - j];
-#endif
-#ifdef CTC_R16_EXP_NOWRITE
-            step(e, j % 4 == 3, wb);
-#else
             step(e, j % 4 == 3, wb + (FWD ? j : kLast - j));
-#endif
         }
         rb += D * kBlockSteps;
         wb += D * kBlockSteps;
@@ -273,7 +189,6 @@ __device__ __forceinline__ void r16_chain(const NoblankParams &p, const R16Smem 
     lds_order();
     *prog = i;
     wait_upto(Tb - 1);
-    if (FAST) rescale(i);
     // the rest in groups of kPrefetch steps = one revolution of the ring (no guards inside).  The
     // last group may run up to three steps past the end: those read zero pad cells and write pad
     // cells of the output rows, which nobody looks at -- the final state is read back below.
@@ -293,57 +208,90 @@ __device__ __forceinline__ void r16_chain(const NoblankParams &p, const R16Smem 
     *prog = Tb;
     __builtin_amdgcn_s_setprio(0);
     // alpha[T_b-1, L_b-1] from where the chain stored it (the registers may hold overrun steps)
-    const cell_t fin = (FWD ? sm.al : sm.be)[(size_t)(L - 1) * sm.TP + (FWD ? Tb - 1 : 0)];
-    afin = as_double(fin);
-    kfin = FAST ? krow[FWD ? Tb - 1 : 0] : 0;
-    cfin = fin;
+    return (FWD ? sm.al : sm.be)[(size_t)(L - 1) * sm.TP + (FWD ? Tb - 1 : 0)];
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's global
-// stores to be acknowledged (s_waitcnt vmcnt(0)) -- more than a microsecond for a worker that has just
-// streamed its gradient rows out, and nobody in the workgroup reads those.
-__device__ __forceinline__ void lds_barrier()
+template <int CH2>
+__global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams p)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// The fast pass's self-check: all live rows must report the same log2 row total, and nothing may
-// have underflowed.  Workers fold their extremes into two LDS words (fixed point, 2^-20 units, integer
-// atomics: 4 lanes per worker); after the common barrier every wave reads the two words.
-constexpr double kVerdictScale = 1048576.0;                  // 2^20
-__device__ __forceinline__ long long verdict_fix(double r)   // +-inf / NaN / far values saturate
-{
-    const double q = r * kVerdictScale;
-    return q > -4.0e18 ? (q < 4.0e18 ? (long long)q : 0x7fffffffffffffffLL) : (long long)0x8000000000000000ULL;
-}
-__device__ __forceinline__ bool r16_verdict(const R16Smem &sm)
-{
-    const long long mn = *reinterpret_cast<const long long *>(sm.vmin), mx = *reinterpret_cast<const long long *>(sm.vmax);
-    // tolerance 1e-4 in log2 units ~ 105 steps of 2^-20; an empty set (no live row) passes
-    return mn > (long long)0x8000000000000000ULL && mx < 0x7fffffffffffffffLL && (mx < mn || mx - mn <= 105);
-}
-
-// One pass over the sample: FAST = doubles under a common scale (returns whether the result is
-// to be trusted), !FAST = extended-range cells (always right).  `v` holds this lane's rows (raw
-// logits on entry), all waves of the workgroup call it together; the caller has zeroed the
-// progress counters and passed a barrier.
-template <int CH2, bool FAST>
-__device__ __forceinline__ bool r16_pass(const NoblankParams &p, const R16Smem &sm, f2_t (&v)[kPipeRows / 4][CH2],
-                                         const int (&tv)[kPipeRows / 4], int b, int u, int w, int Tb, int L,
-                                         bool col_ok)
-{
-    constexpr int RP = 32 * CH2;
-    constexpr int G = kPipeRows / 4;
-    const int lane = lane_id();
-    const int rho = lane >> 4, i16 = lane & 15;
-    const int c_lane = 2 * i16;
+    extern __shared__ float4 smem_raw[];
+    constexpr int RP = 32 * CH2;                             // floats per staged row
+    constexpr int G = kPipeRows / 4;                         // groups of four rows per worker
+    const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, RP);
+    const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int u = (w == 0 || w == kChainB) ? -1 : (w < kChainB ? w - 1 : w - 2);
+    const int rho = lane >> 4, i16 = lane & 15;              // row of the group, position inside the row
     const float ninf = -__builtin_inff();
+
+    if (p.stop == 1) return;                                 // diagnostic: cost of the bare dispatch
+    stamp(p, 0);
+    auto spread = [&](int which) {                           // diagnostic (stop == -50): entry / exit times of
+        if (p.stop != -50 || w != 1 || lane != 0) return;    // the first, middle and last workgroup, wave 1
+        const int bid = blockIdx.x, nb = gridDim.x;
+        const int slot = bid == 0 ? 0 : bid == nb / 2 ? 2 : bid == nb - 1 ? 4 : -1;
+        if (slot < 0) return;
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * (slot + which);
+        o[0] = __builtin_amdgcn_s_memtime();
+        o[1] = __builtin_amdgcn_s_memrealtime();
+    };
+    spread(0);
+    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
+    const int raw_label = tid < p.S ? load_label(p.lab, p.lab64, (int64_t)b * p.S + tid) : 0;
+    // this lane's row in each group, its columns: pairs (32j + 2i, 32j + 2i + 1)
+    int tv[G];
+    f2_t v[G][CH2];
+    const int c_lane = 2 * i16;
+    const bool col_ok = 32 * (CH2 - 1) + c_lane < p.C;       // last pair inside the row (C is even)
+    const int c_last = col_ok ? 32 * (CH2 - 1) + c_lane : p.C - 2;
+    if (u >= 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            tv[g] = pipe_row(p.T, u, 4 * g + rho);
+            const float *row = row_ptr(p, tv[g] >= 0 ? tv[g] : 0, b);
+#pragma unroll
+            for (int j = 0; j < CH2; ++j)
+                v[g][j] = *reinterpret_cast<const f2_t *>(row + (j < CH2 - 1 ? 32 * j + c_lane : c_last));
+        }
+    }
+    // (LDS initialisation that needs no loaded value goes first: it overlaps the loads' latency)
     const cell_t zero = make_cell(0.f, 0);
+    for (int i = tid; i < (p.SP + 1) * sm.TP; i += kThreads) sm.em[i - kR16Pad] = zero;   // pads + spare row
+    if (tid < 16) sm.cnt[tid] = 0;
+    if (tid < 8) sm.dummy[tid] = 0.f;
+    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
+    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
+    if (tid < p.SP) {
+        int k = 0;
+        if (tid < L) {
+            k = raw_label % p.C;
+            if (k < 0) k += p.C;                             // python negative index (NoBlankCTC.py:102)
+        }
+        sm.lab[tid] = k;
+    }
+    __syncthreads();
+    stamp(p, 1);
+    if (p.stop == 2) return;                                 // diagnostic: dispatch + setup (+ loads in flight)
+
+    if (Tb == 0) {                                           // no alignment exists: nll = 1e13, zero gradient
+        if (w == 0)
+            publish_and_reduce(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
+        if (u >= 0 && p.grad) {
+            const f2_t zero2 = {0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (tv[g] < 0) continue;
+                float *gp = p.grad + ((int64_t)tv[g] * p.B + b) * p.C + c_lane;
+#pragma unroll
+                for (int j = 0; j < CH2; ++j)
+                    if (j < CH2 - 1 || col_ok) __builtin_nontemporal_store(zero2, reinterpret_cast<f2_t *>(gp + 32 * j));
+            }
+        }
+        return;
+    }
     typedef const volatile __attribute__((address_space(3))) int lds_cvint;
 
     // ---------------------------------------------------------------- chain waves
     if (u < 0) {
-        float nll = -kNeg;
         if (w == 0) {
             // while the first rows are on their way: occurrence index of every state among equal
             // labels (0 = first).  Repeated labels add up in the workers' occupancy tiles, one
@@ -363,46 +311,17 @@ __device__ __forceinline__ bool r16_pass(const NoblankParams &p, const R16Smem &
                 sm.occ[(p.SP + 3) & ~3] = mo;
                 lds_order();
             }
-            double af0;
-            int kf;
-            cell_t cf;
-            r16_chain<true, FAST>(p, sm, p.T, Tb, L, p.SP, af0, kf, cf);
+            const cell_t a = r16_chain<true>(p, sm, p.T, Tb, L, p.SP);
             stamp(p, 11);
-            if (FAST) {
-                // log2 P = log2 alpha[T_b-1, L_b-1] + the per-row normalisers taken out of the emissions
-                const double af = af0;
-                float cs = 0.f;
-                for (int t = lane; t < Tb; t += kWave) cs += sm.cs[t];
-                cs = wave_sum(cs);
-                const float l2 = __builtin_amdgcn_logf((float)__builtin_amdgcn_frexp_mant(af)) +
-                                 (float)(__builtin_amdgcn_frexp_exp(af) + kf);
-                nll = af > 0.0 ? -(l2 + cs) * kLn2 : -kNeg;
-            } else {
-                const float am = cf.x;
-                const int ak = cell_k(cf);
-                nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(ak - kXrBias)) * kLn2 : -kNeg;
-            }
+            // nll = -log alpha[T_b-1, L_b-1] (NoBlankCTC.py:58-68,139)
+            const float am = a.x;
+            const float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(cell_k(a) - kXrBias)) * kLn2 : -kNeg;
+            publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
         } else if (p.grad) {
-            double af0;
-            int kf;
-            cell_t cf;
-            r16_chain<false, FAST>(p, sm, p.T, Tb, L, p.SP, af0, kf, cf);
+            r16_chain<false>(p, sm, p.T, Tb, L, p.SP);
             stamp(p, 11);
         }
-        bool good = true;
-        if (FAST && p.r16_mode == 3) return true;            // experiment: chains without workers behind them
-        if (w == 0) publish_value(nll, b, p.nll);            // write-through store now, the ticket after the verdict
-        if (FAST) {                                          // the workers' verdict (see below)
-            if (p.stop <= -60) stamp(p, 2);
-            lds_barrier();
-            if (p.stop <= -60) stamp(p, 3);
-            good = r16_verdict(sm) && p.r16_mode != 2;
-            if (p.stop <= -60) stamp(p, 4);
-        }
-        if (w == 0 && good)
-            ticket_and_reduce(p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
-        if (p.stop <= -60) stamp(p, 5);
-        return good;
+        return;
     }
 
     // ---------------------------------------------------------------- workers
@@ -418,8 +337,8 @@ __device__ __forceinline__ bool r16_pass(const NoblankParams &p, const R16Smem &
     }
     const bool own[2] = {lst[0] < L, lst[1] < L};
     const float maskv = col_ok ? 0.f : ninf;
+    cell_t *const spare_w = reinterpret_cast<cell_t *>(sm.dummy);
     float rs[G];                                             // grad_scale / sum_c exp(x - max), 0 for dead rows
-    bool flushed = false;                                    // fast pass: a label probability underflowed
 #pragma unroll
     for (int g = 0; g < G; ++g) {                            // P1: extremes first
         f2_t *x = v[g];
@@ -452,43 +371,24 @@ __device__ __forceinline__ bool r16_pass(const NoblankParams &p, const R16Smem &
         const float l2sum = __builtin_amdgcn_logf(sum);
         rs[g] = live ? p.grad_scale * __builtin_amdgcn_rcpf(sum) : 0.f;
         // emissions e = log_softmax(x)[lab_l] in log2 units, split into 2^floor * 2^frac
-        float e2[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) e2[s] = __builtin_fmaf(xv[s] - m, kLog2e, -l2sum);
-        if (FAST) {
-            float emx = fmaxf(own[0] ? e2[0] : ninf, own[1] ? e2[1] : ninf);
-            row16_allmax(emx);                               // the row's most probable label
-            if (live) sm.cs[t] = emx;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const float d = fmaxf(e2[s] - emx, -1100.f);
-                const float fl = __builtin_floorf(d);
-                const double ph = __builtin_ldexp((double)__builtin_amdgcn_exp2f(d - fl), (int)fl);
-                flushed |= live && own[s] && ph == 0.0;
-                double *dst = (live && lst[s] < p.SP) ? sm.emd + lst[s] * sm.TP + t : reinterpret_cast<double *>(sm.dummy);
-                *dst = own[s] ? ph : 0.0;
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const float ec = fmaxf(e2[s], kXrMinLog2);
-                const float fl = __builtin_floorf(ec);
-                const float pm = __builtin_amdgcn_exp2f(ec - fl);
-                cell_t *dst = (live && lst[s] < p.SP) ? sm.em + lst[s] * sm.TP + t : reinterpret_cast<cell_t *>(sm.dummy);
-                *dst = own[s] ? make_cell(pm, (int)fl) : zero;
-            }
+        for (int s = 0; s < 2; ++s) {
+            const float e2 = fmaxf(__builtin_fmaf(xv[s] - m, kLog2e, -l2sum), kXrMinLog2);
+            const float fl = __builtin_floorf(e2);
+            const float pm = __builtin_amdgcn_exp2f(e2 - fl);
+            cell_t *dst = (live && lst[s] < p.SP) ? sm.em + lst[s] * sm.TP + t : spare_w;
+            *dst = own[s] ? make_cell(pm, (int)fl) : zero;
         }
         lds_order();
         sm.cnt[u] = 4 * (g + 1);                             // publishes the four slots (same wave: in order)
     }
     stamp(p, 2);
-    if (!p.grad || p.r16_mode == 3) return true;
+    if (!p.grad) return;
 
     const int Tlive = Tb;
     const float gsc = p.grad_scale;
     const cell_t *const zero_r = sm.em + (size_t)p.SP * sm.TP;   // the spare state row of em stays zero
     const f2_t zero2 = {0.f, 0.f};
-    double rmin = __builtin_inf(), rmax = -__builtin_inf();  // fast pass: extremes of the log2 row totals
 
     // P3: middle-out, one look at the chains' progress per group
 #pragma unroll
@@ -519,49 +419,25 @@ __device__ __forceinline__ bool r16_pass(const NoblankParams &p, const R16Smem &
         f2_t *x = v[g];
         const int t = tv[g];
         const bool live = t >= 0 && t < Tlive;
-        float z[2], tot;
-        if (FAST) {
-            // gamma_t(l) = alpha_t(l) beta_t(l) / sum_l' (...): the common scales cancel inside a row
-            double pr[2];
+        // gamma_t(l) = alpha_t(l) beta_t(l) / sum_l' (...): mantissa products, exponents added and
+        // shifted by the row's largest
+        float pr[2];
+        int ks[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bool in = live && lst[s] < p.SP;
-                const int off = lst[s] * sm.TP + t;
-                const double *zr = reinterpret_cast<const double *>(zero_r);
-                pr[s] = *(in ? sm.ald + off : zr) * *(in ? sm.bed + off : zr);
-            }
-            int eh = max(__double2hiint(pr[0]), __double2hiint(pr[1])) >> 20;   // largest exponent field
-            row16_allmax(eh);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) z[s] = (float)__builtin_ldexp(pr[s], 1023 - eh);
-            tot = z[0] + z[1];
-            row16_allsum(tot);
-            // log2 of the row total in absolute terms: must be the same number for every live row
-            const int tc = live ? t : 0;
-            const double rho2 = (double)__builtin_amdgcn_logf(tot) + (double)(eh - 1023 + sm.ka[tc] + sm.kb[tc]);
-            const double lo = tot > 0.f ? rho2 : -__builtin_inf();
-            rmin = live ? fmin(rmin, lo) : rmin;
-            rmax = live ? fmax(rmax, lo) : rmax;
-        } else {
-            // the same with (mantissa, exponent) cells: mantissa products, exponents added and
-            // shifted by the row's largest
-            float pr[2];
-            int ks[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bool in = live && lst[s] < p.SP;
-                const int off = lst[s] * sm.TP + t;
-                const cell_t a = *(in ? sm.al + off : zero_r), bb = *(in ? sm.be + off : zero_r);
-                pr[s] = a.x * bb.x;
-                ks[s] = cell_k(a) + cell_k(bb);
-            }
-            int km = max(pr[0] > 0.f ? ks[0] : 0, pr[1] > 0.f ? ks[1] : 0);
-            row16_allmax(km);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) z[s] = __builtin_amdgcn_ldexpf(pr[s], ks[s] - km);
-            tot = z[0] + z[1];
-            row16_allsum(tot);
+        for (int s = 0; s < 2; ++s) {
+            const bool in = live && lst[s] < p.SP;
+            const int off = lst[s] * sm.TP + t;
+            const cell_t a = *(in ? sm.al + off : zero_r), bb = *(in ? sm.be + off : zero_r);
+            pr[s] = a.x * bb.x;
+            ks[s] = cell_k(a) + cell_k(bb);
         }
+        int km = max(pr[0] > 0.f ? ks[0] : 0, pr[1] > 0.f ? ks[1] : 0);
+        row16_allmax(km);
+        float z[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) z[s] = __builtin_amdgcn_ldexpf(pr[s], ks[s] - km);
+        float tot = z[0] + z[1];
+        row16_allsum(tot);
         const float rinv = (live && tot > 0.f) ? gsc * __builtin_amdgcn_rcpf(tot) : 0.f;
         // class occupancy of the four rows: zero the tile, scatter the scaled posteriors
 #pragma unroll
@@ -593,119 +469,42 @@ __device__ __forceinline__ bool r16_pass(const NoblankParams &p, const R16Smem &
         lds_order();
     }
     stamp(p, 7);
-    if (!FAST) return true;
-
-    // verdict: every lane of a 16-lane row carries that row set's extremes; all waves meet, then
-    // each forms the workgroup's answer from the 4 x 14 slots
-    if (flushed) rmin = -__builtin_inf();
-    if (i16 == 0 && rmax >= rmin) {                          // (a row set without live rows has nothing to say)
-        atomicMin(reinterpret_cast<long long *>(sm.vmin), verdict_fix(rmin));
-        atomicMax(reinterpret_cast<long long *>(sm.vmax), verdict_fix(rmax));
-    }
-    if (i16 == 0 && flushed) atomicMin(reinterpret_cast<long long *>(sm.vmin), (long long)0x8000000000000000ULL);
-    if (p.stop <= -60) stamp(p, 2);
-    lds_barrier();
-    if (p.stop <= -60) stamp(p, 3);
-    return r16_verdict(sm) && p.r16_mode != 2;
-}
-
-template <int CH2>
-__global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams p)
-{
-    extern __shared__ float4 smem_raw[];
-    constexpr int RP = 32 * CH2;                             // floats per staged row
-    constexpr int G = kPipeRows / 4;                         // groups of four rows per worker
-    const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, RP);
-    const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    const int u = (w == 0 || w == kChainB) ? -1 : (w < kChainB ? w - 1 : w - 2);
-    const int rho = lane >> 4, i16 = lane & 15;              // row of the group, position inside the row
-
-    if (p.stop == 1) return;                                 // diagnostic: cost of the bare dispatch
-    stamp(p, 0);
-    auto spread = [&](int which) {                           // diagnostic (stop == -50): entry / exit times of
-        if (p.stop != -50 || w != 1 || lane != 0) return;    // the first, middle and last workgroup, wave 1
-        const int bid = blockIdx.x, nb = gridDim.x;
-        const int slot = bid == 0 ? 0 : bid == nb / 2 ? 2 : bid == nb - 1 ? 4 : -1;
-        if (slot < 0) return;
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * (slot + which);
-        o[0] = __builtin_amdgcn_s_memtime();
-        o[1] = __builtin_amdgcn_s_memrealtime();
-    };
-    spread(0);
-    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
-    const int raw_label = tid < p.S ? load_label(p.lab, p.lab64, (int64_t)b * p.S + tid) : 0;
-    // this lane's row in each group, its columns: pairs (32j + 2i, 32j + 2i + 1)
-    int tv[G];
-    f2_t v[G][CH2];
-    const int c_lane = 2 * i16;
-    const bool col_ok = 32 * (CH2 - 1) + c_lane < p.C;       // last pair inside the row (C is even)
-    const int c_last = col_ok ? 32 * (CH2 - 1) + c_lane : p.C - 2;
-    auto load_rows = [&]() {
-        if (u < 0) return;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            tv[g] = pipe_row(p.T, u, 4 * g + rho);
-            const float *row = row_ptr(p, tv[g] >= 0 ? tv[g] : 0, b);
-#pragma unroll
-            for (int j = 0; j < CH2; ++j)
-                v[g][j] = *reinterpret_cast<const f2_t *>(row + (j < CH2 - 1 ? 32 * j + c_lane : c_last));
-        }
-    };
-    load_rows();
-    // (LDS initialisation that needs no loaded value goes first: it overlaps the loads' latency)
-    const cell_t zero = make_cell(0.f, 0);
-    for (int i = tid; i < (p.SP + 1) * sm.TP; i += kThreads) sm.em[i - kR16Pad] = zero;   // pads + spare row
-    if (tid < 16) sm.cnt[tid] = 0;
-    if (tid < 8) sm.dummy[tid] = 0.f;
-    if (tid == 0) {
-        *reinterpret_cast<long long *>(sm.vmin) = 0x7fffffffffffffffLL;
-        *reinterpret_cast<long long *>(sm.vmax) = (long long)0x8000000000000001ULL;
-    }
-    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
-    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
-
-    if (tid < p.SP) {
-        int k = 0;
-        if (tid < L) {
-            k = raw_label % p.C;
-            if (k < 0) k += p.C;                             // python negative index (NoBlankCTC.py:102)
-        }
-        sm.lab[tid] = k;
-    }
-    __syncthreads();
-    stamp(p, 1);
-    if (p.stop == 2) return;                                 // diagnostic: dispatch + setup (+ loads in flight)
-
-    if (Tb == 0) {                                           // no alignment exists: nll = 1e13, zero gradient
-        if (w == 0)
-            publish_and_reduce(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
-        if (u >= 0 && p.grad) {
-            const f2_t zero2 = {0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (tv[g] < 0) continue;
-                float *gp = p.grad + ((int64_t)tv[g] * p.B + b) * p.C + c_lane;
-#pragma unroll
-                for (int j = 0; j < CH2; ++j)
-                    if (j < CH2 - 1 || col_ok) __builtin_nontemporal_store(zero2, reinterpret_cast<f2_t *>(gp + 32 * j));
-            }
-        }
-        return;
-    }
-
-    // fast pass (doubles, common scale) when a gradient is wanted -- its self-check needs both chains;
-    // (CTC_AMD_R16_MODE = 1 / 2, diagnostics: go straight to the robust pass / distrust the fast one)
-    if (p.grad && p.r16_mode != 1) {
-        if (r16_pass<CH2, true>(p, sm, v, tv, b, u, w, Tb, L, col_ok)) {
-            spread(1);
-            return;
-        }
-        if (tid < 16) sm.cnt[tid] = 0;                       // distrusted: once more, with per-state exponents
-        load_rows();
-        __syncthreads();
-    }
-    r16_pass<CH2, false>(p, sm, v, tv, b, u, w, Tb, L, col_ok);
     spread(1);
 }
 
+// ---- diagnostic probe (tools/chain_probe.py): the chains alone, every row already published ------
+__global__ __launch_bounds__(kThreads, 4) void r16_chain_probe_kernel(NoblankParams p, unsigned long long *out, int waves_alive)
+{
+    extern __shared__ float4 smem_raw[];
+    const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, 32);
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    for (int i = tid; i < 3 * (p.SP + 1) * sm.TP; i += kThreads) sm.em[i - kR16Pad] = make_cell(1.5f, -1);
+    if (tid < 16) sm.cnt[tid] = kPipeRows;                   // everything published
+    __syncthreads();
+    if (w >= waves_alive) return;
+    if (w > 1) {                                             // bystanders: poll like a waiting worker
+        typedef const volatile __attribute__((address_space(3))) int lds_cvint;
+        int spins = 0;
+        while (*(lds_cvint *)(sm.cnt + kPipeWorkers) < p.T && ++spins < 100000) __builtin_amdgcn_s_sleep(8);
+        return;
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const cell_t c = w == 0 ? r16_chain<true>(p, sm, p.T, p.T, p.SP, p.SP) : r16_chain<false>(p, sm, p.T, p.T, p.SP, p.SP);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) {
+        out[w] = t1 - t0;
+        out[4 + w] = (unsigned long long)cell_k(c);
+    }
+}
+
 }  // namespace ctc
+
+extern "C" int ctc_amd_debug_chain_probe(int T, int SP, int waves_alive, int grid, void *out, void *stream)
+{
+    using namespace ctc;
+    NoblankParams p = {};
+    p.T = T; p.SP = SP; p.S = SP; p.B = grid; p.C = 32; p.stop = 0;
+    const size_t smem = r16_smem_bytes(T, SP, 158);
+    return launch<r16_chain_probe_kernel>(dim3(grid), dim3(kThreads), smem, static_cast<hipStream_t>(stream), p,
+                                          static_cast<unsigned long long *>(out), waves_alive);
+}

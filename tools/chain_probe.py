@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Diagnostic: the lattice chain of noblank_r16.hpp alone (all rows pre-published), cycles per step."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ctc_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+fn = lib.ctc_amd_debug_chain_probe
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
+out = torch.zeros(16, dtype=torch.int64, device="cuda")
+T, SP = 150, 20
+for waves, grid in ((1, 1), (2, 1), (16, 1), (1, 256), (2, 256), (16, 256)):
+    for _ in range(3):
+        out.zero_()
+        rc = fn(T, SP, waves, grid, out.data_ptr(), None)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+    o = out.cpu().tolist()
+    print("waves_alive=%2d grid=%3d: alpha %6d cyc (%5.1f/step)  beta %6d cyc (%5.1f/step)"
+          % (waves, grid, o[0], o[0] / (T - 1), o[1], o[1] / (T - 1)))

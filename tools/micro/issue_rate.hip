@@ -19,7 +19,7 @@
         ((int *)lds)[threadIdx.x & 63] = (threadIdx.x * 4) % 256; lds[(threadIdx.x & 63) + 64] = 1.f;                      \
         float v0 = threadIdx.x, v1 = 1.0001f, v2 = 3.f, v3 = 4.f, v4 = 5.f, v5 = 6.f, v6 = 7.f, v7 = 8.f; \
         int i0 = threadIdx.x, i1 = 3, i2 = 5, i3 = (threadIdx.x & 63) < 20 ? (threadIdx.x & 63) * 8 : 1024;                                      \
-        int addr = (threadIdx.x & 63) * 8 + (int)out[3];                                                        \
+        int addr = (threadIdx.x & 63) * (out[4] ? (int)out[4] : 8) + (int)out[3]; if (out[5] && (threadIdx.x & 63) >= out[5]) return;                                                        \
         __syncthreads();                                                                   \
         unsigned long long t0 = __builtin_amdgcn_s_memtime();                             \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
@@ -145,7 +145,7 @@ BENCH(f64_chain_nowait, 12,
 )
 
 typedef void (*kern_t)(unsigned long long *, float *, float *);
-struct Entry { const char *name; kern_t k; int waves; int grid; int solo; int ldsb; int off; };
+struct Entry { const char *name; kern_t k; int waves; int grid; int solo; int ldsb; int off; int pitch; int lanes; };
 #define E(n) {#n, n, 1, 1, 0, 16384, 0}
 #define EW(n, w) {#n " x" #w " waves", n, w, 1, 0, 16384, 0}
 #define EG(n, w, g, so) {#n " " #w "w grid" #g " solo" #so, n, w, g, so, 16384, 0}
@@ -155,7 +155,7 @@ int main()
 {
     unsigned long long *out;
     float *sink;
-    if (hipMalloc(&out, 64) != hipSuccess || hipMalloc(&sink, 4096) != hipSuccess) return 1;
+    if (hipMalloc(&out, 256) != hipSuccess || hipMalloc(&sink, 4096) != hipSuccess) return 1;
     std::vector<Entry> es = {E(dep_add), E(indep_add), E(dep_mul), E(dep_ldexp), E(indep_ldexp), E(dep_maxi), E(dep_maxi_dpp),
                              E(dep_mov_dpp), E(dep_mov_dpp_rowshr), E(dep_add_dpp_rowshr), E(dep_add_dpp_waveshr), E(dep_exp),
                              E(indep_exp), E(dep_log), E(dep_frexp), E(dep_fma), E(dep_cndmask), E(lds_read_dep), E(lds_rw_indep),
@@ -167,13 +167,19 @@ int main()
                              EW(f64_chain_real, 2), EW(f64_chain_real, 16), EG(f64_chain_real, 1, 256, 0), EG(f64_chain_real, 16, 1, 1),
                              EG(f64_chain_real, 16, 256, 1), EG(f64_chain_real, 2, 256, 0), EG(dep_add, 1, 256, 0), EG(dep_add, 16, 256, 1), EG(f64_step, 16, 256, 1),
                              EL(f64_chain_real, 143360, 0), EL(f64_chain_real, 143360, 65536), EL(f64_chain_real, 143360, 131072),
-                             EL(lds_r_distinct, 143360, 0), EL(lds_r_distinct, 143360, 131072), EL(lds_w_distinct, 143360, 131072), EL(lds_read_dep, 143360, 0)};
+                             EL(lds_r_distinct, 143360, 0), EL(lds_r_distinct, 143360, 131072), EL(lds_w_distinct, 143360, 131072), EL(lds_read_dep, 143360, 0),
+                             {"f64_chain_real pitch1416 lanes20", f64_chain_real, 1, 1, 0, 143360, 0, 1416, 20},
+                             {"f64_chain_real pitch1416 lanes64", f64_chain_real, 1, 1, 0, 143360, 0, 1416, 64},
+                             {"f64_chain_real pitch8 lanes20", f64_chain_real, 1, 1, 0, 143360, 0, 8, 20},
+                             {"lds_w_distinct pitch1416 lanes20", lds_w_distinct, 1, 1, 0, 143360, 0, 1416, 20},
+                             {"lds_r_distinct pitch1416 lanes20", lds_r_distinct, 1, 1, 0, 143360, 0, 1416, 20},
+                             {"lds_rw_indep pitch1416 lanes20", lds_rw_indep, 1, 1, 0, 143360, 0, 1416, 20}};
     for (auto &e : es) {
         unsigned long long h[2] = {0, 0};
         for (int r = 0; r < 3; ++r) {
-            unsigned long long cfg[2] = {(unsigned long long)e.solo, (unsigned long long)e.off};
+            unsigned long long cfg[4] = {(unsigned long long)e.solo, (unsigned long long)e.off, (unsigned long long)e.pitch, (unsigned long long)e.lanes};
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 4;
-            if (hipMemcpy(out + 2, cfg, 16, hipMemcpyHostToDevice) != hipSuccess) return 3;
+            if (hipMemcpy(out + 2, cfg, 32, hipMemcpyHostToDevice) != hipSuccess) return 3;
             hipLaunchKernelGGL(e.k, dim3(e.grid), dim3(64 * e.waves), e.ldsb, 0, out, sink, sink);
             if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, out, 16, hipMemcpyDeviceToHost) != hipSuccess) return 2;
         }
