@@ -175,7 +175,7 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     for (; i + kBlockSteps <= Tb; i += kBlockSteps) {
         lds_order();
         *prog = i;                                           // steps < i are done (every lane, same value)
-        wait_upto(i + kBlockSteps - 1 + kPrefetch);
+        if (have < G) wait_upto(i + kBlockSteps - 1 + kPrefetch);
         if (p.stop < 0) stamp(p, 2 + i / kBlockSteps);       // diagnostic: block starts -> slots 2..10
 #pragma unroll
         for (int j = 0; j < kBlockSteps; ++j) {
@@ -188,7 +188,7 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     }
     lds_order();
     *prog = i;
-    wait_upto(Tb - 1);
+    if (have < G) wait_upto(Tb - 1);
     // the rest in groups of kPrefetch steps = one revolution of the ring (no guards inside).  The
     // last group may run up to three steps past the end: those read zero pad cells and write pad
     // cells of the output rows, which nobody looks at -- the final state is read back below.
@@ -268,7 +268,9 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         }
         sm.lab[tid] = k;
     }
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also wait for every row load of the wave (s_waitcnt
+    // vmcnt(0)), but a worker only needs its first group's rows to start
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     stamp(p, 1);
     if (p.stop == 2) return;                                 // diagnostic: dispatch + setup (+ loads in flight)
 

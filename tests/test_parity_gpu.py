@@ -303,6 +303,50 @@ def test_noblank_kernel_path_boundaries(dev, shape):
     assert_close(r, ref, 2e-6 * max(1.0, 256.0 / B))
 
 
+@pytest.mark.parametrize("shape", [
+    (168, 3, 256, 31),   # largest shape of the four-rows-per-wave kernel (noblank_r16.hpp): T, C, S at their limits
+    (150, 2, 158, 20),   # config-2 shape
+    (9, 2, 2, 5),        # one column pair per row
+    (40, 2, 34, 17),     # second pass of states (l >= 16) barely used, last column pair partly masked
+    (33, 4, 64, 16),     # exactly one pass of states
+])
+def test_noblank_r16_kernel_cases(dev, shape):
+    """Cases aimed at the four-rows-per-wave kernel: repeated labels (occupancy accumulation in
+    several passes), a single label, T_b = L_b (one alignment), dead tail rows, non-contiguous logits."""
+    import ctc_amd
+    T, B, C, S = shape
+    x, lab, Tb, L = synth_noblank(5 + sum(shape), T, B, C, S, var_T=True)
+    L = torch.minimum(L, Tb)
+    lab[0, :] = 1 % C                                           # every state the same class
+    if B > 1:
+        L[1] = 1                                                # a single state
+    if B > 2:
+        Tb[2] = L[2]                                            # exactly one alignment
+    ref = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+    assert_close(r, ref, 2e-6 * max(1.0, 256.0 / B))
+    for b, tb in enumerate(np_(Tb)):
+        assert np.abs(r["grad"][int(tb):, b]).max(initial=0.0) == 0.0
+    # the same through a strided view (every second sample of a wider buffer: strides stay even)
+    wide = torch.zeros(T, 2 * B, C)
+    wide[:, ::2] = x
+    xd = wide.to(dev)[:, ::2].requires_grad_(True)
+    loss, nll = ctc_amd.noblank_ctc_loss(xd, lab.to(dev), Tb.to(dev), L.to(dev))
+    assert np.array_equal(np_(nll), r["nll"])
+
+
+def test_noblank_extreme_logits_keep_full_range(dev):
+    """State contrasts far beyond fp32 range (logits x 200: per-sample nll ~ 1e5) -- the lattice
+    cells carry their own exponents, so nothing underflows and nothing is approximated."""
+    import ctc_amd
+    x, lab, Tb, L = synth_noblank(3, 150, 16, 158, 20, var_T=True)
+    x = x * 200.0
+    ref = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+    assert np.isfinite(r["nll"]).all() and (r["nll"] > 1e3).all()
+    assert_close(r, ref, 2e-5 * (256.0 / 16), nll_rtol=1e-6)
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1, 1), (170, 2, 40, 12), (160, 2, 158, 20), (30, 2, 257, 6),
                                    (30, 3, 64, 64), (20, 2, 30, 70)])
 def test_binary_kernel_path_boundaries(dev, shape):
