@@ -44,7 +44,7 @@ __device__ __forceinline__ int cell_k(cell_t c)
 
 struct XrSmem {
     cell_t *em, *al, *be;
-    float *dummy;
+    float *dummy, *rs;
     int *cnt, *lab, *nxt, *dup, *inv;
     __device__ XrSmem(float *base, int T, int SP, int C)
     {
@@ -58,6 +58,7 @@ struct XrSmem {
         nxt = lab + SP;
         dup = nxt + SP;
         inv = dup + SP;
+        rs = reinterpret_cast<float *>(inv + C + 4);         // [workers][slots]: 1/sum of the rows (DUAL build)
     }
     // the scaled posterior of row t overwrites the first half of that row's beta cells (same
     // worker wave, after it has read them)
@@ -66,7 +67,7 @@ struct XrSmem {
 
 static size_t xr_smem_bytes(int T, int SP, int C)
 {
-    return (size_t)(3 * T + 2 * kPrefetch) * SP * 8 + noblank_tables_bytes(SP, C);
+    return (size_t)(3 * T + 2 * kPrefetch) * SP * 8 + noblank_tables_bytes(SP, C) + kPipeWorkers * kPipeRows * 4;
 }
 
 // neighbour state through DPP, lanes without a neighbour read 0 (= no mass, exponent -inf)
@@ -265,7 +266,11 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_xr_kernel(Nobl
     const float mask_tail = lane + 64 * (CH - 1) < p.C ? 0.f : ninf;
     const int lab_l = lane < p.SP ? sm.lab[lane] : 0;
     const int lab_src = lab_l & 63, lab_chunk = lab_l >> 6;
-    float rsrow[kPipeRows];
+    // grad_scale / sum_c exp(x - max) per slot: registers with one workgroup per CU; in the 64-VGPR
+    // build they go to LDS (12 registers fewer: without that the build spills 10 VGPRs to scratch,
+    // i.e. to HBM -- measured +40 % memory traffic at B = 2048)
+    float rsrow[DUAL ? 1 : kPipeRows];
+    float *const rs_lds = sm.rs + u * kPipeRows;
 #pragma unroll
     for (int gq = 0; gq < kPipeRows / kGroup; ++gq) {        // P1: extremes first
         float m[kGroup], sum[kGroup];
@@ -302,8 +307,12 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_xr_kernel(Nobl
             const int r = gq * kGroup + k;
             const int t = pipe_row(p.T, u, r);
             const float l2sum = __builtin_amdgcn_logf(sum[k]);
-            rsrow[r] = p.grad_scale * __builtin_amdgcn_rcpf(sum[k]);
-            asm volatile("" : "+v"(rsrow[r]));
+            if (DUAL) {
+                rs_lds[r] = p.grad_scale * __builtin_amdgcn_rcpf(sum[k]);    // (every lane, same value)
+            } else {
+                rsrow[r] = p.grad_scale * __builtin_amdgcn_rcpf(sum[k]);
+                asm volatile("" : "+v"(rsrow[r]));
+            }
             // emission e = log_softmax(x)[lab_l] in log2 units, split into 2^floor * 2^frac
             const float e2 = fmaxf(__builtin_fmaf(xv[k] - m[k], kLog2e, -l2sum), kXrMinLog2);
             const float fl = __builtin_floorf(e2);
@@ -478,11 +487,12 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_xr_kernel(Nobl
                 continue;
             }
             const float *gr = sm.grow(t, p.SP);
+            const float rsr = DUAL ? rs_lds[r] : rsrow[r];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const int c = lane + 64 * j;
                 const float occ = gr[first[j]];
-                const float gv = __builtin_fmaf(v[r][j], rsrow[r], has[j] ? -occ : 0.f);
+                const float gv = __builtin_fmaf(v[r][j], rsr, has[j] ? -occ : 0.f);
                 if (j < CH - 1 || c < p.C) stream_store(&g[c], gv);
             }
         }
