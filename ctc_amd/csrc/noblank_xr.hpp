@@ -325,9 +325,6 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_xr_kernel(Nobl
     }
     stamp(p, 2);
     if (!p.grad) return;
-#ifdef CTC_XR_NOP3
-    return;                                                  // experiment: chains without competing workers
-#endif
 
     if (u == kPipeWorkers - 1) {
         for (int c = lane; c < p.C; c += kWave) sm.inv[c] = 0x7fffffff;
