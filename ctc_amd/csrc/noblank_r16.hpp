@@ -45,19 +45,25 @@ __device__ __forceinline__ void row16_allmax(float &v) { asm volatile(CTC_ROW16(
 __device__ __forceinline__ void row16_allsum(float &v) { asm volatile(CTC_ROW16("v_add_f32_dpp") : "+v"(v)); }
 __device__ __forceinline__ void row16_allmax(int &v) { asm volatile(CTC_ROW16("v_max_i32_dpp") : "+v"(v)); }
 
-// Lattice layout of this kernel: TRANSPOSED, [state][time] with time contiguous -- cell (t, l) of
-// each of the three arrays sits at l * TP + t (8-byte cells).  A chain lane then walks its own
-// row with a compile-time stride, so the loads / stores of an unrolled block of steps use
-// immediate offsets (no address arithmetic per step), and the pitch TP = 1 (mod 16) cells keeps
-// both the chains' accesses (lanes = states, same t) and the workers' (16 states of four rows)
-// free of bank conflicts.  Every state row has kR16Pad zero cells before t = 0 and after t = T-1
-// (the chains' prefetch and the last, partly idle group of four steps run past the ends), and there is one spare state row SP: all zeros in
-// `em` (idle chain lanes read it), scratch in `al` / `be` (idle lanes write it).
-constexpr int kR16Pad = 2 * kPrefetch;                      // prefetch depth + up to 3 steps of tail overrun
+// Lattice layout of this kernel: TRANSPOSED, [state][time] with time contiguous -- cell t of state l
+// sits at l * TP + kR16Pad + t (8-byte cells) in each of the three arrays.  A chain lane then walks
+// its own row with a compile-time stride, so the loads / stores of an unrolled block of steps use
+// immediate offsets (no address arithmetic per step), and TWO consecutive steps move as ONE 16-byte
+// LDS access (the chain is bound by its LDS instructions, not by its arithmetic): the pad is odd so
+// that the forward pairs (steps 1-2, 3-4, ...) start on 16-byte boundaries; beta_t is stored one
+// cell further (at kR16Pad + 1 + t), which makes a beta step read and write the SAME cell index
+// (it reads the emissions of row t+1 and writes row t), its pairs aligned whenever the alpha pairs
+// of that parity are (one single step is peeled off when T_b is even).  Pitch TP = 2 (mod 4)
+// cells: 16-byte aligned rows, and the lanes of a chain access (4 banks each, stride 2 TP words)
+// fall on different banks.  kR16Pad cells before t = 0 and after t = T-1 of every state row
+// take the chains' prefetch (4 steps ahead) and the last, partly idle group of four steps (up to 3
+// steps past the end); `em` pads are zero.  One spare state row SP: all zeros in `em` (read by
+// the chain lanes that only watch progress counters), scratch in `al` / `be`.
+constexpr int kR16Pad = 2 * kPrefetch + 1;                  // odd
 __host__ __device__ inline int r16_pitch(int T)
 {
-    int tp = T + 2 * kR16Pad;
-    while ((tp & 15) != 1) ++tp;
+    int tp = T + 2 * kR16Pad + 1;
+    while ((tp & 3) != 2) ++tp;
     return tp;
 }
 
@@ -72,7 +78,7 @@ struct R16Smem {
         cell_t *lat = reinterpret_cast<cell_t *>(base);
         em = lat + kR16Pad;                                  // -> cell (t = 0, l = 0)
         al = em + (size_t)(SP + 1) * TP;
-        be = al + (size_t)(SP + 1) * TP;
+        be = al + (size_t)(SP + 1) * TP + 1;                 // beta_t one cell further (see above)
         dummy = reinterpret_cast<float *>(lat + (size_t)3 * (SP + 1) * TP);   // write-only spare cells
         cnt = reinterpret_cast<int *>(dummy + 8);
         lab = cnt + 16;
@@ -105,12 +111,13 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     // from a disabled lane is the zero the first / last state needs anyway (bound_ctrl)
     if (lane >= (SP > kPipeWorkers ? SP : kPipeWorkers)) return make_cell(0.f, 0);
     const int lrow = lane < SP ? lane : SP;                  // counter-only lanes: the spare state row
-    const int t_first = FWD ? 0 : Tb - 1;
-    const cell_t *rd = sm.em + (size_t)lrow * sm.TP + t_first;
-    cell_t *wr = (FWD ? sm.al : sm.be) + (size_t)lrow * sm.TP + t_first;
+    // step i = 1..T_b-1 reads the emissions of row tr(i) = FWD ? i : T_b - i and writes row
+    // FWD ? i : T_b - 1 - i -- both at cell index x(i) = FWD ? i : T_b - i of their arrays
+    const cell_t *erow = sm.em + (size_t)lrow * sm.TP;
+    cell_t *orow = (FWD ? sm.al : sm.be - 1) + (size_t)lrow * sm.TP;   // (be - 1: index x, not t)
+    typedef float pair_t __attribute__((ext_vector_type(4)));           // two cells: (lower, higher) time index
     float m;
     int k;
-    cell_t ring[kPrefetch];
 
     const int H = (T + 1) >> 1;
     const int pos0 = FWD ? 0 : T - Tb;                       // position (in this chain's half order) of step 0
@@ -137,54 +144,76 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
         m = __builtin_amdgcn_ldexpf(m, k - kk) + __builtin_amdgcn_ldexpf(nm, nk - kk);
         k = kk;
     };
-    auto step = [&](cell_t ec, bool norm, cell_t *dst) {
+    auto step = [&](float em_, float ek_, bool norm) {       // one time step with emission (em_, ek_)
         if (FWD) merge();
-        m *= ec.x;
-        k += cell_k(ec);
+        m *= em_;
+        k += __builtin_bit_cast(int, ek_);
         if (norm) {                                          // mantissa back into [0.5, 1)
             k += __builtin_amdgcn_frexp_expf(m);
             m = __builtin_amdgcn_frexp_mantf(m);
         }
         if (!FWD) merge();
-        *dst = make_cell(m, k);
+    };
+    // steps (i, i+1) with the pair of emission cells `e` (lower, higher index); returns the pair to store
+    auto step2 = [&](pair_t e, bool norm_second) {
+        pair_t o;
+        step(FWD ? e.x : e.z, FWD ? e.y : e.w, false);
+        const float m1 = m;
+        const int k1 = k;
+        step(FWD ? e.z : e.x, FWD ? e.w : e.y, norm_second);
+        const float k1f = __builtin_bit_cast(float, k1), k2f = __builtin_bit_cast(float, k);
+        o.x = FWD ? m1 : m;  o.y = FWD ? k1f : k2f;          // lower index: the earlier step when walking up
+        o.z = FWD ? m : m1;  o.w = FWD ? k2f : k1f;
+        return o;
     };
 
     int *prog = sm.cnt + kPipeWorkers + (FWD ? 0 : 1);
     __builtin_amdgcn_s_setprio(3);                           // the chains are the critical path
-    wait_upto(kPrefetch);
+    wait_upto(kPrefetch + 1);
+    int i = 1;
     if (FWD) {                                               // alpha_0 = p_0(0) on state 0 only
-        const cell_t e0 = *rd;
-        rd += D;
+        const cell_t e0 = erow[0];
         m = lane == 0 ? e0.x : 0.f;
         k = lane == 0 ? kXrBias + cell_k(e0) : 0;
+        orow[0] = make_cell(m, k);
     } else {                                                 // beta_{T_b-1} = 1 on state L-1 only
         m = lane == L - 1 ? 1.f : 0.f;
         k = lane == L - 1 ? kXrBias : 0;
+        orow[Tb] = make_cell(m, k);
+        if ((Tb & 1) == 0 && Tb > 1) {                       // align the pairs: one single step (wave-uniform)
+            const cell_t e = erow[Tb - 1];
+            step(e.x, e.y, false);
+            orow[Tb - 1] = make_cell(m, k);
+            i = 2;
+        }
     }
-    *wr = make_cell(m, k);
-    wr += D;
-#pragma unroll
-    for (int j = 0; j < kPrefetch; ++j) ring[j] = rd[D * j];
-    rd += D * kPrefetch;
-    // block-relative bases at the LOWEST address of the block, so that the unrolled steps use
-    // non-negative immediate offsets in both directions (ds offsets are unsigned)
-    constexpr int kLast = kBlockSteps - 1;
-    const cell_t *rb = FWD ? rd : rd - kLast;
-    cell_t *wb = FWD ? wr : wr - kLast;
-    int i = 1;
+    // x(i) of the current step, and the lowest cell index of the pair (i, i+1): even by construction
+    const int x0 = FWD ? i : Tb - i;
+    constexpr int kPairs = kBlockSteps / 2;
+    // block-relative bases at the LOWEST address a block touches, so that the unrolled pairs use
+    // non-negative immediate offsets in both directions (ds offsets are unsigned).  The reads run
+    // kPrefetch steps (two pairs) ahead of the writes.
+    const pair_t *rb = reinterpret_cast<const pair_t *>(erow + (FWD ? x0 + kPrefetch : x0 - kPrefetch - (kBlockSteps - 1)));
+    pair_t *wb = reinterpret_cast<pair_t *>(orow + (FWD ? x0 : x0 - (kBlockSteps - 1)));
+    pair_t ring[2];
+    {
+        const pair_t *r0 = reinterpret_cast<const pair_t *>(erow + (FWD ? x0 : x0 - 3));
+        ring[0] = r0[FWD ? 0 : 1];                           // steps i, i+1
+        ring[1] = r0[FWD ? 1 : 0];                           // steps i+2, i+3
+    }
     for (; i + kBlockSteps <= Tb; i += kBlockSteps) {
         lds_order();
         *prog = i;                                           // steps < i are done (every lane, same value)
         if (have < G) wait_upto(i + kBlockSteps - 1 + kPrefetch);
         if (p.stop < 0) stamp(p, 2 + i / kBlockSteps);       // diagnostic: block starts -> slots 2..10
 #pragma unroll
-        for (int j = 0; j < kBlockSteps; ++j) {
-            const cell_t e = ring[j % kPrefetch];
-            ring[j % kPrefetch] = rb[FWD ? j : kLast - j];
-            step(e, j % 4 == 3, wb + (FWD ? j : kLast - j));
+        for (int q = 0; q < kPairs; ++q) {
+            const pair_t e = ring[q & 1];
+            ring[q & 1] = rb[FWD ? q : kPairs - 1 - q];
+            wb[FWD ? q : kPairs - 1 - q] = step2(e, (q & 1) == 1);
         }
-        rb += D * kBlockSteps;
-        wb += D * kBlockSteps;
+        rb += D * kPairs;
+        wb += D * kPairs;
     }
     lds_order();
     *prog = i;
@@ -193,16 +222,16 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     // last group may run up to three steps past the end: those read zero pad cells and write pad
     // cells of the output rows, which nobody looks at -- the final state is read back below.
     static_assert(kPrefetch == 4, "tail groups assume one ring revolution = one renormalisation period");
-    if (!FWD) { rb += kLast - (kPrefetch - 1); wb += kLast - (kPrefetch - 1); }   // lowest address of a 4-step group
+    if (!FWD) { rb += kPairs - 2; wb += kPairs - 2; }        // lowest address of a 4-step group
     for (; i < Tb; i += kPrefetch) {
 #pragma unroll
-        for (int j = 0; j < kPrefetch; ++j) {
-            const cell_t e = ring[j];
-            ring[j] = rb[FWD ? j : kPrefetch - 1 - j];
-            step(e, j == kPrefetch - 1, wb + (FWD ? j : kPrefetch - 1 - j));
+        for (int q = 0; q < 2; ++q) {
+            const pair_t e = ring[q];
+            ring[q] = rb[FWD ? q : 1 - q];
+            wb[FWD ? q : 1 - q] = step2(e, q == 1);
         }
-        rb += D * kPrefetch;
-        wb += D * kPrefetch;
+        rb += D * 2;
+        wb += D * 2;
     }
     lds_order();
     *prog = Tb;
