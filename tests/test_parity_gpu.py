@@ -335,6 +335,24 @@ def test_noblank_r16_kernel_cases(dev, shape):
     assert np.array_equal(np_(nll), r["nll"])
 
 
+def test_noblank_r16_small_shape_sweep(dev):
+    """Seeded sweep over small shapes the four-rows-per-wave kernel accepts (C even): every T parity
+    (the beta chain peels one step when T_b is even), T_b from 1, single states, S up to 31."""
+    import ctc_amd
+    rng = np.random.RandomState(7)
+    for case in range(48):
+        T = int(rng.randint(1, 41))
+        B = int(rng.randint(1, 5))
+        C = 2 * int(rng.randint(1, 40))
+        S = int(rng.randint(1, 32))
+        x, lab, Tb, L = synth_noblank(1000 + case, T, B, C, S, var_T=False)
+        Tb = torch.from_numpy(rng.randint(1, T + 1, size=B)).long()
+        L = torch.minimum(torch.minimum(L, Tb), torch.tensor(S))
+        ref = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+        r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+        assert_close(r, ref, 2e-6 * 256.0 / B)
+
+
 def test_noblank_extreme_logits_keep_full_range(dev):
     """State contrasts far beyond fp32 range (logits x 200: per-sample nll ~ 1e5) -- the lattice
     cells carry their own exponents, so nothing underflows and nothing is approximated."""
