@@ -579,3 +579,16 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
         default: return launch_noblank<4>(ch, smem, s, p);
     }
 }
+
+// Diagnostic entry point (tools/chain_probe.py), not part of include/ctc_amd.h: the lattice chains of
+// noblank_r16.hpp alone, every emission row pre-published; out[0], out[1] = shader cycles of the
+// alpha / beta chain.
+extern "C" int ctc_amd_debug_chain_probe(int T, int SP, int waves_alive, int grid, void *out, void *stream)
+{
+    using namespace ctc;
+    NoblankParams p = {};
+    p.T = T; p.SP = SP; p.S = SP; p.B = grid; p.C = 32; p.stop = 0;
+    const size_t smem = r16_smem_bytes(T, SP, 158);
+    return launch<r16_chain_probe_kernel>(dim3(grid), dim3(kThreads), smem, static_cast<hipStream_t>(stream), p,
+                                          static_cast<unsigned long long *>(out), waves_alive);
+}

@@ -348,6 +348,15 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             const float am = a.x;
             const float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(cell_k(a) - kXrBias)) * kLn2 : -kNeg;
             publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
+            if (p.stop == -50 && lane == 0) {                // diagnostic: when the alpha wave (loss ticket) is done
+                const int bid = blockIdx.x, nb = gridDim.x;
+                const int slot = bid == 0 ? 6 : bid == nb / 2 ? 7 : bid == nb - 1 ? 8 : -1;
+                if (slot >= 0) {
+                    unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
+                    o[0] = __builtin_amdgcn_s_memtime();
+                    o[1] = __builtin_amdgcn_s_memrealtime();
+                }
+            }
         } else if (p.grad) {
             r16_chain<false>(p, sm, p.T, Tb, L, p.SP);
             stamp(p, 11);
@@ -529,13 +538,3 @@ __global__ __launch_bounds__(kThreads, 4) void r16_chain_probe_kernel(NoblankPar
 }
 
 }  // namespace ctc
-
-extern "C" int ctc_amd_debug_chain_probe(int T, int SP, int waves_alive, int grid, void *out, void *stream)
-{
-    using namespace ctc;
-    NoblankParams p = {};
-    p.T = T; p.SP = SP; p.S = SP; p.B = grid; p.C = 32; p.stop = 0;
-    const size_t smem = r16_smem_bytes(T, SP, 158);
-    return launch<r16_chain_probe_kernel>(dim3(grid), dim3(kThreads), smem, static_cast<hipStream_t>(stream), p,
-                                          static_cast<unsigned long long *>(out), waves_alive);
-}

@@ -28,8 +28,10 @@ torch.cuda.synchronize()
 st = ws.cpu().numpy()[64:64 + 12 * 16].view(np.uint64).reshape(12, 2).astype(np.int64)
 if os.environ.get("CTC_AMD_DEBUG_STOP") == "-50":
     names = ["first wg entry", "first wg exit", "middle wg entry", "middle wg exit", "last wg entry", "last wg exit"]
-    for i in range(6):
-        print("  %-16s %7.2f us (realtime, relative to the first workgroup's entry)" % (names[i], (st[i][1] - st[0][1]) / 100.0))
+    names += ["first wg alpha wave done", "middle wg alpha wave done", "last wg alpha wave done"]
+    for i in range(9):
+        if st[i][1] > 0:
+            print("  %-26s %7.2f us (realtime, relative to the first workgroup's entry)" % (names[i], (st[i][1] - st[0][1]) / 100.0))
     sys.exit(0)
 print("slot: us since entry (slots mean different things per kernel/wave, see the kernel source)")
 for i in range(12):
