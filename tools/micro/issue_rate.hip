@@ -144,6 +144,10 @@ BENCH(f64_chain_nowait, 12,
       "v_fma_f64 v[24:25], v[28:29], v[20:21], v[24:25]\n\t"
 )
 
+// LDS float atomics (no return): distinct addresses / all lanes on one address
+BENCH(lds_add_f32_distinct, 1, "ds_add_f32 %12, v22 offset:2048\n\t")
+BENCH(lds_add_f32_same, 1, "ds_add_f32 %11, v22 offset:2048\n\t")
+
 typedef void (*kern_t)(unsigned long long *, float *, float *);
 struct Entry { const char *name; kern_t k; int waves; int grid; int solo; int ldsb; int off; int pitch; int lanes; };
 #define E(n) {#n, n, 1, 1, 0, 16384, 0}
@@ -173,7 +177,10 @@ int main()
                              {"f64_chain_real pitch8 lanes20", f64_chain_real, 1, 1, 0, 143360, 0, 8, 20},
                              {"lds_w_distinct pitch1416 lanes20", lds_w_distinct, 1, 1, 0, 143360, 0, 1416, 20},
                              {"lds_r_distinct pitch1416 lanes20", lds_r_distinct, 1, 1, 0, 143360, 0, 1416, 20},
-                             {"lds_rw_indep pitch1416 lanes20", lds_rw_indep, 1, 1, 0, 143360, 0, 1416, 20}};
+                             {"lds_rw_indep pitch1416 lanes20", lds_rw_indep, 1, 1, 0, 143360, 0, 1416, 20},
+                             E(lds_add_f32_distinct), E(lds_add_f32_same),
+                             {"lds_add_f32_distinct lanes20", lds_add_f32_distinct, 1, 1, 0, 16384, 0, 8, 20},
+                             {"lds_add_f32_distinct 16 waves", lds_add_f32_distinct, 16, 1, 0, 16384, 0, 8, 0}};
     for (auto &e : es) {
         unsigned long long h[2] = {0, 0};
         for (int r = 0; r < 3; ++r) {
