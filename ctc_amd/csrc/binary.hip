@@ -65,16 +65,26 @@ __device__ __forceinline__ void bce_logs(float x, float &p, float &lp, float &lq
     lq = fmaxf(logf(1.0f - p), -100.0f);
 }
 
-// same, with the raw v_log_f32 for the two logs: p itself still comes from the accurate expf
-// (where 1-p cancels, the reference's value depends on the last bit of p), while a log only has
-// to be good to ~1e-7 relative, which the hardware op is
+// The same numbers with fewer instructions (the logs of the MFMA kernel are pure VALU throughput):
+//   * exp(-x): the library expf's own algorithm (product split into a round-to-nearest integer and
+//     a compensated fraction, v_exp_f32, v_ldexp_f32) without its range clamps -- beyond them the
+//     plain sequence already yields inf / 0 / a denormal, which is what the clamps return; p
+//     itself must be the library's value to the last bit (where 1 - p cancels, the reference's
+//     log(1 - p) depends on it);
+//   * log p = x - log1p(e^x) equals x to fp32 precision for x < -30 (and v_log_f32 does not take
+//     the denormal p of x < -87): a select instead of a divergent branch; log(1 - p) on the raw
+//     v_log_f32 (1 - p is either 0 or >= 2^-24), which is good to ~1e-7 relative.
 __device__ __forceinline__ void bce_logs_fast(float x, float &p, float &lp, float &lq)
 {
-    p = __builtin_amdgcn_rcpf(1.0f + expf(-x));
+    const float t = x * -kLog2e;
+    const float n = __builtin_rintf(t);
+    float r = __builtin_fmaf(x, -kLog2e, -t);                // rounding error of the product
+    r = __builtin_fmaf(x, -1.92596299e-8f, r);               // + x * (low part of -log2 e)
+    const float e = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f((t - n) + r), (int)n);
+    p = __builtin_amdgcn_rcpf(1.0f + e);
     const float one_m_p = 1.0f - p;
-    // v_log_f32 does not handle denormals: p >= 2^-126 unless x < -87 (then log p <= -87 anyway
-    // and the clamp below is what matters only beyond -100: use the accurate path there)
-    lp = x < -80.0f ? fmaxf(logf(p), -100.0f) : __builtin_amdgcn_logf(p) * kLn2;
+    const float lp_raw = __builtin_amdgcn_logf(p) * kLn2;
+    lp = x < -30.0f ? fmaxf(x, -100.0f) : lp_raw;
     lq = one_m_p > 0.0f ? fmaxf(__builtin_amdgcn_logf(one_m_p) * kLn2, -100.0f) : -100.0f;
 }
 
