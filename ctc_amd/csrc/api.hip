@@ -1,7 +1,10 @@
 // C-ABI entry points that are not tied to one kernel file (include/ctc_amd.h).
 #include "launch.hpp"
 
-namespace ctc { size_t noblank_extra_workspace(int T, int B, int C, int S); }   // noblank.hip
+namespace ctc {
+size_t noblank_extra_workspace(int T, int B, int C, int S);   // noblank.hip
+int blank_sync_ints(int T, int B);                              // blank.hip
+}
 
 extern "C" int ctc_amd_abi_version(void) { return CTC_AMD_ABI_VERSION; }
 
@@ -20,11 +23,13 @@ extern "C" size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int 
     // [0,256): arrival counter of the in-launch batch reduction (+ padding)
     size_t bytes = 256;
     if (variant == CTC_AMD_BLANK) {
-        // emissions, alpha, beta lattices [B][T][NSP] fp32 + three [B][NSP] int state tables;
-        // NSP = 2S+1 padded to 64*K states (K = 2, 4, 8 states per lane), see blank.hip
+        // emissions, alpha, beta lattices [B][T][NSP] fp32 + three [B][NSP] int state tables + [B] int2 lengths
+        // + the hand-off counters of the fused schedule; NSP = 2S+1 padded to 64*K states (K = 2, 4, 8
+        // states per lane), see blank.hip
         const size_t ns = 2 * (size_t)S + 1;
         const size_t nsp = ns <= 128 ? 128 : (ns <= 256 ? 256 : 512);
-        bytes += 3 * (size_t)B * (size_t)T * nsp * sizeof(float) + 3 * (size_t)B * nsp * sizeof(int);
+        bytes += 3 * (size_t)B * (size_t)T * nsp * sizeof(float) + 3 * (size_t)B * nsp * sizeof(int) +
+                 (2 * (((size_t)B + 63) & ~(size_t)63) + (size_t)ctc::blank_sync_ints(T, B)) * sizeof(int);
     }
     if (variant == CTC_AMD_NOBLANK) bytes += ctc::noblank_extra_workspace(T, B, C, S);   // 0 while T x S fits in LDS
     return bytes;

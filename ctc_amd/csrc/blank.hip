@@ -8,24 +8,66 @@
 //   grad[t,c] = (exp(lp[t,c]) - sum_{s: l'_s = c} gamma_t(s)) * grad_scale / max(L,1), 0 for t >= T_b.
 //
 // T x (2S+1) does not fit in LDS (config 5: 2000 x 201), so the lattice lives in the
-// caller's workspace and the work is split where the parallelism changes:
-//   K0 gather   (wide, all CUs)  em[b,t,s] = lp[t,b,l'_s]: rows of lp are read whole and
-//                                coalesced once; per-sample state tables are built here
-//   K1 chains   (one WG / sample) wave 0 = alpha, wave 1 = beta, K states per lane, the two
-//                                neighbour states through DPP wave shifts, emission rows
-//                                prefetched 8 deep from the workspace; writes alpha, beta
-//   K2 grad     (wide)           one wave per (t,b) row: gamma_t = softmax_s(alpha+beta-e)
-//                                (row-normalised, see lattice.hpp), folded per class
-//                                (blank by a wave reduction, repeated labels by the
-//                                first-occurrence chain), then the dense row
-//                                exp(lp) - occupancy with coalesced loads / stores.
+// caller's workspace.  Three kinds of work with different shapes:
+//   gather  (bandwidth)   em[b,t,s] = lp[t,b,l'_s]: rows of lp are read once, in whole lines
+//   chains  (latency)     one workgroup per sample, wave 0 = alpha, wave 1 = beta, K states per
+//                         lane, the two neighbour states through DPP wave shifts, emission rows
+//                         prefetched 64/K deep; T dependent steps of ~150 ns each
+//   grad    (bandwidth)   one wave per (t,b) row: gamma_t = softmax_s(alpha+beta-e)
+//                         (row-normalised, see lattice.hpp), folded per class (blank by a wave
+//                         reduction, repeated labels by the first-occurrence chain), then the
+//                         dense row exp(lp) - occupancy with coalesced loads / stores.
+//
+// Two schedules:
+//  * three launches (blank_gather_kernel, blank_chain_kernel, blank_grad_kernel), the chains
+//    alone on 2 B waves while 250 CUs idle -- forward-only calls, short sequences, batches too
+//    large for the second schedule;
+//  * ONE persistent launch (blank_fused_kernel, after the tiny blank_tables_kernel) of one
+//    512-thread workgroup per CU.  Workgroups [0, B) own one sample each: waves 0 / 1 run the
+//    alpha / beta chains and touch nothing but LDS and their write-only lattice rows; four loader
+//    waves (on the other two SIMDs) gather the emission rows straight from log_probs, dozens of
+//    rows ahead, into an LDS ring per direction -- the emissions never go to HBM, and no load
+//    latency sits on the chains (beta rows are stored WITHOUT their own emission, so
+//    gamma = alpha + beta' needs no emission either).  All other workgroups are row workers:
+//    they turn a row into gradient as soon as BOTH chains have passed it (the chains cross in
+//    the middle of the sample, so rows become ready from the middle outwards, two per step),
+//    in that order.  Hand-off chains -> workers: `steps landed` per sample and direction in the
+//    workspace.  Forward progress needs every workgroup resident at once: the grid is at most
+//    one workgroup per CU (the LDS request makes that the occupancy too), and chain workgroups
+//    have the lowest block indices, so they are placed first.  All waits are bounded
+//    (kSpinLimit); a wait that runs out raises the status word and poisons its outputs with NaN.
+//    Cross-XCD visibility (each XCD has its own L2): lattice rows are written with agent-scope
+//    (sc1, write-through) stores and read with sc1 loads; the counters are agent-scope atomics.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "launch.hpp"
 
 namespace ctc {
 
 constexpr float kNegB = -1.0e30f;    // finite stand-in for -inf inside the scans
-constexpr int kDepth = 8;            // emission rows in flight ahead of a chain
+constexpr int kRingRegs = 64;        // three-launch chains: VGPRs of emission rows in flight (64/K rows;
+                                     // 8 rows stalled the chain on HBM latency, 16 rows gained 7 %)
+constexpr int kSpinLimit = 1 << 18;  // polls before a wait gives up
+constexpr int kSyncHead = 64;        // ints in front of the counters (status word, chains finished)
+constexpr int kProgPitch = 32;       // ints between two progress counters: one 128-byte line each (they are polled)
+constexpr int kAuxAgent = 16;        // buffer-instruction cache policy: sc1 = agent scope
+constexpr int kFusedMinT = 128;      // shorter sequences keep the three-launch schedule
+constexpr int kMaxV4 = 4;            // float4 per lane that cover a row of the VEC4 paths (C <= 1024)
+constexpr int kFusedWaves = 8;       // waves of a workgroup of the fused launch
+constexpr int kRingRows = 128;       // x 1/K: emission rows per direction in the LDS ring (32 KB for every K)
+constexpr int kLoadAhead = 12;       // rows each loader wave keeps in flight
+constexpr int kLoaders = 3;          // loader waves per direction (two could not keep up: the chains waited 30 % of the time)
+constexpr int kGroup = 8;            // chain steps between hand-off checks
+constexpr int kLandLag = 48;         // lattice stores that may still be in flight when progress is published
+constexpr size_t kFusedLdsHead = 64; // bytes of LDS flags in front of the rings
+
+// ints of hand-off state behind the per-sample tables (see BlankParams::sync)
+int blank_sync_ints(int T, int B)
+{
+    (void)T;
+    return kSyncHead + 2 * ((B + 63) & ~63) * kProgPitch;
+}
 
 struct BlankParams {
     const float *lp;
@@ -40,6 +82,12 @@ struct BlankParams {
     float *em, *al, *be;             // [B][T][NSP] each
     int *cls, *nxt, *first;          // [B][NSP]: class of state s; next state with the same class;
                                      // 1 when s is the first state carrying its (non-blank) class
+    int2 *meta;                      // [B] (T_b, or 0 when there is no alignment: T_b < L_b + adjacent repeats; L_b)
+    // fused schedule: sync[0] status, sync[1] chains finished, sync[kSyncHead + (dir Bp + b) kProgPitch]
+    // steps of chain `dir` of sample b whose lattice rows have landed
+    int *sync;
+    int Bp, nsync;
+    int debug;                       // CTC_AMD_BLANK_DEBUG (diagnostics: 128 = timeline stamps)
 };
 
 __device__ __forceinline__ bool blank_sample_ok(const BlankParams &p, int b, int &Tb, int &L)
@@ -51,15 +99,102 @@ __device__ __forceinline__ bool blank_sample_ok(const BlankParams &p, int b, int
     return ok;
 }
 
-// ---- K0: state tables + emission gather -------------------------------------------------
-__global__ __launch_bounds__(256) void blank_gather_kernel(BlankParams p, int rows_per_block)
+// ---- hand-off primitives of the fused schedule ------------------------------------------------------
+__device__ __forceinline__ int agent_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// true once *flag >= target; false when the bounded wait ran out (status word raised).  The flags
+// count chain steps, so the distance to the target says how long to stay away: a thousand waves
+// polling one cache line flat out would tie up its memory channel.
+__device__ __forceinline__ bool wait_ge(const BlankParams &p, const int *flag, int target)
 {
-    extern __shared__ int s_cls[];                           // [NSP]
-    const int b = blockIdx.y, tid = threadIdx.x;
-    int Tb, L;
-    blank_sample_ok(p, b, Tb, L);
-    const int n = 2 * L + 1;
-    for (int s = tid; s < p.NSP; s += blockDim.x) {
+    bool ok = false;
+    for (int it = 0; it < kSpinLimit; ++it) {
+        const int v = agent_load(flag);
+        if (v >= target) { ok = true; break; }
+        if (v < 0 || ((it & 255) == 255 && agent_load(p.sync) != 0)) break;   // the producer gave up / somebody did
+        const int naps = max(min(target - v, 64), 24);       // ~ one nap (40 x 64 clocks, 1 us) per 8 missing steps, 3 to 8
+        for (int q = 0; q < naps; q += 8) __builtin_amdgcn_s_sleep(40);
+    }
+    if (!ok) agent_store(p.sync, 1);
+    asm volatile("" ::: "memory");                           // nothing below moves above the poll
+    return ok;
+}
+
+// the same inside a workgroup, on a flag in LDS (another wave of the workgroup bumps it)
+__device__ __forceinline__ int wg_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wg_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (`seen`: the last value read, so that the caller only comes back when it needs more)
+__device__ __forceinline__ bool lds_wait_ge(const BlankParams &p, const int *flag, int target, int &seen)
+{
+    bool ok = false;
+    for (int it = 0; it < kSpinLimit; ++it) {
+        seen = wg_load(flag);
+        if (seen >= target) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) agent_store(p.sync, 1);
+    asm volatile("" ::: "memory");
+    return ok;
+}
+
+// diagnostics (CTC_AMD_BLANK_DEBUG & 128): 100-MHz timestamps into workspace bytes [64,256), tools/blank_stamps.py
+__device__ __forceinline__ void bstamp(const BlankParams &p, int slot)
+{
+    if (!(p.debug & 128) || lane_id() != 0 || slot >= 24) return;
+    reinterpret_cast<unsigned long long *>(p.counter)[8 + slot] = __builtin_amdgcn_s_memrealtime();
+}
+
+typedef int i4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef int i2_t __attribute__((ext_vector_type(2)));
+
+// one sample's [T][NSP] lattice as a raw buffer (bounds-checked by the hardware)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lattice_rsrc(const float *base, int T, int NSP)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, T * NSP * (int)sizeof(float), 0x00020000);
+}
+template <int K>
+__device__ __forceinline__ void agent_store_row(__amdgpu_buffer_rsrc_t r, int byte_off, const float (&a)[K])
+{
+    if constexpr (K == 2) {
+        const i2_t v = {__builtin_bit_cast(int, a[0]), __builtin_bit_cast(int, a[1])};
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, kAuxAgent);
+    } else {
+#pragma unroll
+        for (int q = 0; q < K; q += 4) {
+            const i4_t v = {__builtin_bit_cast(int, a[q]), __builtin_bit_cast(int, a[q + 1]),
+                            __builtin_bit_cast(int, a[q + 2]), __builtin_bit_cast(int, a[q + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off + q * 4, 0, kAuxAgent);
+        }
+    }
+}
+template <int K>
+__device__ __forceinline__ void agent_load_row(__amdgpu_buffer_rsrc_t r, int byte_off, float (&a)[K])
+{
+    if constexpr (K == 2) {
+        const i2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, kAuxAgent);
+        const int x = v.x, y = v.y;                          // (element reads of a vector go through temporaries)
+        a[0] = __builtin_bit_cast(float, x);
+        a[1] = __builtin_bit_cast(float, y);
+    } else {
+#pragma unroll
+        for (int q = 0; q < K; q += 4) {
+            const i4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + q * 4, 0, kAuxAgent);
+            const int x = v.x, y = v.y, z = v.z, w = v.w;
+            a[q] = __builtin_bit_cast(float, x);
+            a[q + 1] = __builtin_bit_cast(float, y);
+            a[q + 2] = __builtin_bit_cast(float, z);
+            a[q + 3] = __builtin_bit_cast(float, w);
+        }
+    }
+}
+
+// ---- K0: state tables + emission gather -------------------------------------------------
+// classes of the extended label into LDS (all threads of the block; ends with a barrier)
+__device__ __forceinline__ void blank_classes(const BlankParams &p, int b, int n, int *s_cls)
+{
+    for (int s = threadIdx.x; s < p.NSP; s += blockDim.x) {
         int c = p.blank;
         if (s < n && (s & 1)) {
             c = load_label(p.tgt, p.tgt64, (int64_t)b * p.S + (s >> 1));
@@ -68,19 +203,41 @@ __global__ __launch_bounds__(256) void blank_gather_kernel(BlankParams p, int ro
         s_cls[s] = c;
     }
     __syncthreads();
-    if (blockIdx.x == 0)
-        for (int s = tid; s < p.NSP; s += blockDim.x) {
-            p.cls[b * p.NSP + s] = s_cls[s];
-            int nx = -1;
-            if (s < n && (s & 1))
-                for (int s2 = s + 2; s2 < n; s2 += 2)
-                    if (s_cls[s2] == s_cls[s]) { nx = s2; break; }
-            p.nxt[b * p.NSP + s] = nx;
-            int fi = (s < n && (s & 1)) ? 1 : 0;
-            for (int s2 = 1; fi && s2 < s; s2 += 2)
-                if (s_cls[s2] == s_cls[s]) fi = 0;
-            p.first[b * p.NSP + s] = fi;
-        }
+}
+
+// per-sample state tables + (effective length, target length), from the classes in LDS
+__device__ __forceinline__ void blank_tables(const BlankParams &p, int b, int Tb, int L, const int *s_cls)
+{
+    const int n = 2 * L + 1;
+    for (int s = threadIdx.x; s < p.NSP; s += blockDim.x) {
+        p.cls[b * p.NSP + s] = s_cls[s];
+        int nx = -1;
+        if (s < n && (s & 1))
+            for (int s2 = s + 2; s2 < n; s2 += 2)
+                if (s_cls[s2] == s_cls[s]) { nx = s2; break; }
+        p.nxt[b * p.NSP + s] = nx;
+        int fi = (s < n && (s & 1)) ? 1 : 0;
+        for (int s2 = 1; fi && s2 < s; s2 += 2)
+            if (s_cls[s2] == s_cls[s]) fi = 0;
+        p.first[b * p.NSP + s] = fi;
+    }
+    if (threadIdx.x == 0) {                                  // an alignment needs one step per label plus a blank
+        int need = L;                                        // between every two equal neighbours
+        for (int l = 1; l < L; ++l) need += s_cls[2 * l + 1] == s_cls[2 * l - 1] ? 1 : 0;
+        p.meta[b] = make_int2(Tb >= need ? Tb : 0, L);
+    }
+}
+
+// three-launch schedule.  Grid: (row blocks, B); block x takes rows [x rpb, (x+1) rpb)
+__global__ __launch_bounds__(256) void blank_gather_kernel(BlankParams p, int rows_per_block)
+{
+    extern __shared__ int s_cls[];                           // [NSP]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int Tb, L;
+    blank_sample_ok(p, b, Tb, L);
+    const int n = 2 * L + 1;
+    blank_classes(p, b, n, s_cls);
+    if (blockIdx.x == 0) blank_tables(p, b, Tb, L, s_cls);
     const int t_begin = blockIdx.x * rows_per_block;
     const int t_end = min(t_begin + rows_per_block, Tb);
     for (int t = t_begin; t < t_end; ++t) {
@@ -88,6 +245,18 @@ __global__ __launch_bounds__(256) void blank_gather_kernel(BlankParams p, int ro
         float *out = p.em + ((int64_t)b * p.T + t) * p.NSP;
         for (int s = tid; s < p.NSP; s += blockDim.x) out[s] = s < n ? fmaxf(row[s_cls[s]] * kLog2e, kNegB) : kNegB;
     }
+}
+
+// fused schedule: tables only, and the hand-off counters back to zero.  Grid: B
+__global__ __launch_bounds__(256) void blank_tables_kernel(BlankParams p)
+{
+    extern __shared__ int s_cls[];                           // [NSP]
+    const int b = blockIdx.x;
+    int Tb, L;
+    blank_sample_ok(p, b, Tb, L);
+    blank_classes(p, b, 2 * L + 1, s_cls);
+    blank_tables(p, b, Tb, L, s_cls);
+    for (int i = b * blockDim.x + threadIdx.x; i < p.nsync; i += gridDim.x * blockDim.x) p.sync[i] = 0;
 }
 
 // ---- K1: alpha / beta chains ----------------------------------------------------------------
@@ -106,14 +275,12 @@ __device__ __forceinline__ float lse2_2(float a, float b)
     return m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(a - b)));
 }
 
+// per-lane constants of a chain: which of its K states are real, and which take the s-2 edge
 template <int K, bool FWD>
-__device__ __forceinline__ void blank_chain(const BlankParams &p, int b, int Tb, int L, float (&a)[K])
+__device__ __forceinline__ void blank_state_flags(const BlankParams &p, int b, int n, bool (&skip)[K], bool (&valid)[K])
 {
-    const int lane = lane_id(), s0 = lane * K, n = 2 * L + 1;
-    const float *em = p.em + (int64_t)b * p.T * p.NSP + s0;
-    float *out = (FWD ? p.al : p.be) + (int64_t)b * p.T * p.NSP + s0;
+    const int s0 = lane_id() * K;
     const int *cls = p.cls + b * p.NSP;
-    bool skip[K], valid[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int s = s0 + k;
@@ -122,6 +289,59 @@ __device__ __forceinline__ void blank_chain(const BlankParams &p, int b, int Tb,
         const int s2 = FWD ? s - 2 : s + 2;
         skip[k] = (s & 1) && s2 >= 0 && s2 < n && cls[s] != cls[s2];
     }
+}
+
+// one time step of a chain: a <- LSE of the predecessors + e
+template <int K, bool FWD>
+__device__ __forceinline__ void blank_step(float (&a)[K], const float (&e)[K], const bool (&skip)[K])
+{
+    // neighbour lane's two edge states (alpha: previous lane's last two, beta: next lane's first two)
+    const float n1 = FWD ? wave_shr1(a[K - 1], kNegB) : wave_shl1(a[0], kNegB);
+    const float n2 = FWD ? wave_shr1(a[K - 2], kNegB) : wave_shl1(a[1], kNegB);
+    float nx[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float x1, x2;
+        if (FWD) {
+            x1 = k >= 1 ? a[k - 1] : n1;
+            x2 = k >= 2 ? a[k - 2] : (k == 1 ? n1 : n2);
+        } else {
+            x1 = k + 1 < K ? a[k + 1] : n1;
+            x2 = k + 2 < K ? a[k + 2] : (k + 1 < K ? n1 : n2);
+        }
+        // s = lane*K + k with K even: k even <=> blank state (two predecessors, no skip).
+        // States beyond n carry the sentinel emission and just sink (stay finite: they lose
+        // 1e30 per step, fp32 holds that for any T); no per-state masking or clamping.
+        nx[k] = ((k & 1) ? lse3_2(a[k], x1, skip[k] ? x2 : kNegB) : lse2_2(a[k], x1)) + e[k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = nx[k];
+}
+
+// the first row: the two entry states only
+template <int K, bool FWD>
+__device__ __forceinline__ void blank_first(float (&a)[K], const float (&e0)[K], int n)
+{
+    const int s0 = lane_id() * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int s = s0 + k;
+        const bool entry = FWD ? (s == 0 || s == 1) : (s == n - 1 || s == n - 2);
+        a[k] = (entry && s < n) ? e0[k] : kNegB;
+    }
+}
+
+// Three-launch schedule: one chain over a whole sample, emissions from the workspace (prefetched
+// kRingRegs/K rows ahead), rows with their own emission included into the workspace.
+template <int K, bool FWD>
+__device__ __forceinline__ void blank_chain(const BlankParams &p, int b, int Tb, int L, float (&a)[K])
+{
+    constexpr int D = kRingRegs / K;                         // emission rows in flight
+    const int lane = lane_id(), s0 = lane * K, n = 2 * L + 1;
+    const float *em = p.em + (int64_t)b * p.T * p.NSP + s0;
+    float *out = (FWD ? p.al : p.be) + (int64_t)b * p.T * p.NSP + s0;
+    bool skip[K], valid[K];
+    blank_state_flags<K, FWD>(p, b, n, skip, valid);
     auto row_of = [&](int i) { return FWD ? i : Tb - 1 - i; };
     auto fetch = [&](float (&dst)[K], int i) {
         const float *r = em + (int64_t)row_of(i < Tb ? i : Tb - 1) * p.NSP;
@@ -133,92 +353,316 @@ __device__ __forceinline__ void blank_chain(const BlankParams &p, int b, int Tb,
 #pragma unroll
         for (int k = 0; k < K; ++k) r[k] = a[k];
     };
-    auto step = [&](int i, const float (&e)[K]) {
-        // neighbour lane's two edge states (alpha: previous lane's last two, beta: next lane's first two)
-        const float n1 = FWD ? wave_shr1(a[K - 1], kNegB) : wave_shl1(a[0], kNegB);
-        const float n2 = FWD ? wave_shr1(a[K - 2], kNegB) : wave_shl1(a[1], kNegB);
-        float nx[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            float x1, x2;
-            if (FWD) {
-                x1 = k >= 1 ? a[k - 1] : n1;
-                x2 = k >= 2 ? a[k - 2] : (k == 1 ? n1 : n2);
-            } else {
-                x1 = k + 1 < K ? a[k + 1] : n1;
-                x2 = k + 2 < K ? a[k + 2] : (k + 1 < K ? n1 : n2);
-            }
-            // s = lane*K + k with K even: k even <=> blank state (two predecessors, no skip).
-            // States beyond n carry the sentinel emission and just sink (stay finite: they lose
-            // 1e30 per step, fp32 holds that for any T); no per-state masking or clamping.
-            nx[k] = ((k & 1) ? lse3_2(a[k], x1, skip[k] ? x2 : kNegB) : lse2_2(a[k], x1)) + e[k];
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) a[k] = nx[k];
-        store(i);
-    };
-
-    float ring[kDepth][K];
-    {   // first row: the two entry states only
+    float ring[D][K];
+    {
         float e0[K];
         fetch(e0, 0);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int s = s0 + k;
-            const bool entry = FWD ? (s == 0 || s == 1) : (s == n - 1 || s == n - 2);
-            a[k] = (entry && valid[k]) ? e0[k] : kNegB;
-        }
+        blank_first<K, FWD>(a, e0, n);
         store(0);
     }
-#pragma unroll
-    for (int j = 0; j < kDepth; ++j) fetch(ring[j], 1 + j);
     int i = 1;
-    for (; i + kDepth <= Tb; i += kDepth) {
 #pragma unroll
-        for (int j = 0; j < kDepth; ++j) {
+    for (int j = 0; j < D; ++j) fetch(ring[j], i + j);
+    for (; i + D <= Tb; i += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
             float e[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) e[k] = ring[j][k];
-            fetch(ring[j], i + j + kDepth);
-            step(i + j, e);
+            fetch(ring[j], i + j + D);
+            blank_step<K, FWD>(a, e, skip);
+            store(i + j);
         }
     }
 #pragma unroll
-    for (int j = 0; j < kDepth; ++j)
-        if (i + j < Tb) step(i + j, ring[j]);
+    for (int j = 0; j < D; ++j)
+        if (i + j < Tb) {
+            blank_step<K, FWD>(a, ring[j], skip);
+            store(i + j);
+        }
 }
 
+// ---- fused schedule, the sample's workgroup -------------------------------------------------------
+// LDS of a chain workgroup: flags[4 d + j] rows finished by loader j of direction d (0 alpha,
+// 1 beta), flags[4 d + 3] steps consumed by that chain; then the two rings of kRingRows/K emission
+// rows of NSP floats, row i of a direction in slot i mod ring; then a row of staging per loader.
+struct FusedLds {
+    int *flags;
+    float *ring0;                                            // direction d: ring0 + d * ring_floats
+    int ring_floats;
+    __device__ __forceinline__ float *ring(int dir) const { return ring0 + dir * ring_floats; }
+};
+template <int K>
+__device__ __forceinline__ FusedLds fused_lds(const BlankParams &p, void *base)
+{
+    FusedLds f;
+    f.flags = reinterpret_cast<int *>(base);
+    f.ring0 = reinterpret_cast<float *>(reinterpret_cast<char *>(base) + kFusedLdsHead);
+    f.ring_floats = (kRingRows / K) * p.NSP;
+    return f;
+}
+
+// K consecutive floats of an LDS row, 4 K bytes aligned: one ds_read / ds_write of that width
+template <int K>
+__device__ __forceinline__ void lds_get(const float *src, float (&dst)[K])
+{
+    if constexpr (K == 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(src);
+        dst[0] = v.x; dst[1] = v.y;
+    } else {
+#pragma unroll
+        for (int q = 0; q < K; q += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + q);
+            dst[q] = v.x; dst[q + 1] = v.y; dst[q + 2] = v.z; dst[q + 3] = v.w;
+        }
+    }
+}
+template <int K>
+__device__ __forceinline__ void lds_put(float *dst, const float (&src)[K])
+{
+    if constexpr (K == 2) {
+        *reinterpret_cast<float2 *>(dst) = make_float2(src[0], src[1]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < K; q += 4) *reinterpret_cast<float4 *>(dst + q) = make_float4(src[q], src[q + 1], src[q + 2], src[q + 3]);
+    }
+}
+
+// Loader `j` of direction `dir`: rows j, j+kLoaders, ... of that chain's step order, gathered from
+// log_probs with kLoadAhead rows in flight, converted to log2 units and written to the ring as
+// soon as the chain has left the slot; one counter bump per row.
+template <int K>
+__device__ __forceinline__ void blank_loader(const BlankParams &p, int b, int Tb, int L, int dir, int j, const FusedLds &f)
+{
+    constexpr int R = kRingRows / K, P = kLoadAhead;
+    const int lane = lane_id(), s0 = lane * K, n = 2 * L + 1;
+    const float *base = p.lp + (int64_t)b * p.sb;
+    int c[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) c[k] = p.cls[b * p.NSP + s0 + k];
+    float *ring = f.ring(dir) + s0;
+    int *done_flag = f.flags + 4 * dir + j;
+    const int *consumed = f.flags + 4 * dir + 3;
+    int seen = 0;                                            // steps the chain is known to have consumed
+    auto issue = [&](float (&x)[K], int r) {                 // row r of the step order (clamped: loaded, not used)
+        const int rr = r < Tb ? r : Tb - 1;
+        const float *row = base + (int64_t)(dir == 0 ? rr : Tb - 1 - rr) * p.st;
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[k] = row[c[k]];
+    };
+    float x[P][K];
+#pragma unroll
+    for (int q = 0; q < P; ++q) issue(x[q], j + kLoaders * q);
+    int done = 0;
+    for (int r = j; r < Tb; r += kLoaders * P) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int rr = r + kLoaders * q;
+            if (rr < Tb) {                                   // wave-uniform
+                if (rr - R + 1 > seen && !lds_wait_ge(p, consumed, rr - R + 1, seen)) return;   // slot still being read
+                float e[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) e[k] = s0 + k < n ? fmaxf(x[q][k] * kLog2e, kNegB) : kNegB;
+                lds_put<K>(ring + (rr & (R - 1)) * p.NSP, e);
+                ++done;                                      // (LDS keeps a wave's program order: row, then count)
+                if (lane == 0) wg_store(done_flag, done);
+            }
+            issue(x[q], rr + kLoaders * P);
+        }
+    }
+}
+
+// The same with whole rows: a gather spreads a wave's 64 lanes over up to 64 cache lines and the
+// CU's address path takes them one by one -- two directions at one row per step keep it busy
+// ~95 % of the time and the chains wait.  Here the row comes in as C/4 coalesced float4 (VEC4
+// shapes: C <= 1024, 16-byte aligned rows), goes through this wave's `stage` buffer in LDS and
+// is gathered from there.
+template <int K>
+__device__ __forceinline__ void blank_loader_rows(const BlankParams &p, int b, int Tb, int L, int dir, int j, const FusedLds &f, float *stage)
+{
+    constexpr int R = kRingRows / K, P = kLoadAhead;
+    const int lane = lane_id(), s0 = lane * K, n = 2 * L + 1, c4 = p.C >> 2;
+    const float *base = p.lp + (int64_t)b * p.sb;
+    int c[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) c[k] = p.cls[b * p.NSP + s0 + k];
+    float *ring = f.ring(dir) + s0;
+    int *done_flag = f.flags + 4 * dir + j;
+    const int *consumed = f.flags + 4 * dir + 3;
+    int seen = 0;                                            // steps the chain is known to have consumed
+    auto issue = [&](f4_t (&x)[kMaxV4], int r) {             // row r of the step order (clamped: loaded, not used)
+        const int rr = r < Tb ? r : Tb - 1;
+        const f4_t *row = reinterpret_cast<const f4_t *>(base + (int64_t)(dir == 0 ? rr : Tb - 1 - rr) * p.st);
+#pragma unroll
+        for (int q = 0; q < kMaxV4; ++q) x[q] = row[min(lane + kWave * q, c4 - 1)];   // (past the row: its last float4 again)
+    };
+    auto finish = [&](const f4_t (&x)[kMaxV4], int rr, int &done) {   // false: the wait ran out
+#pragma unroll
+        for (int v = 0; v < kMaxV4; ++v) reinterpret_cast<f4_t *>(stage)[lane + kWave * v] = x[v];   // (stage holds 4 x 64 float4)
+        asm volatile("" ::: "memory");                       // (same wave: LDS keeps program order)
+        float e[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) e[k] = s0 + k < n ? fmaxf(stage[c[k]] * kLog2e, kNegB) : kNegB;
+        if (rr - R + 1 > seen && !lds_wait_ge(p, consumed, rr - R + 1, seen)) return false;   // slot still being read
+        lds_put<K>(ring + (rr & (R - 1)) * p.NSP, e);
+        ++done;                                              // (LDS keeps a wave's program order: row, then count)
+        if (lane == 0) wg_store(done_flag, done);
+        return true;
+    };
+    // kLoadAhead rows in flight, each in its own small array: one big array would stay in scratch
+    // memory (the backend only keeps arrays up to a quarter of the register budget in registers)
+    static_assert(P == 12, "one named buffer per row in flight");
+    f4_t x0[kMaxV4], x1[kMaxV4], x2[kMaxV4], x3[kMaxV4], x4[kMaxV4], x5[kMaxV4], x6[kMaxV4], x7[kMaxV4], x8[kMaxV4],
+        x9[kMaxV4], x10[kMaxV4], x11[kMaxV4];
+#define CTC_EACH_ROW(F) F(0, x0) F(1, x1) F(2, x2) F(3, x3) F(4, x4) F(5, x5) F(6, x6) F(7, x7) F(8, x8) F(9, x9) F(10, x10) F(11, x11)
+#define CTC_FIRST(Q, X) issue(X, j + kLoaders * (Q));
+#define CTC_TURN(Q, X)                                        \
+    {                                                         \
+        const int rr = r + kLoaders * (Q);                    \
+        if (rr < Tb && !finish(X, rr, done)) return;          \
+        issue(X, rr + kLoaders * P);                          \
+    }
+    CTC_EACH_ROW(CTC_FIRST)
+    int done = 0;
+    for (int r = j; r < Tb; r += kLoaders * P) { CTC_EACH_ROW(CTC_TURN) }
+#undef CTC_TURN
+#undef CTC_FIRST
+#undef CTC_EACH_ROW
+}
+
+// One chain of the fused schedule: emissions from the LDS ring, kGroup steps per hand-off check;
+// lattice rows written through to memory (beta WITHOUT its own emission), and the number of steps
+// whose rows have landed published per group.
+template <int K, bool FWD>
+__device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, int Tb, int L, float (&a)[K], const FusedLds &f)
+{
+    constexpr int R = kRingRows / K, G = kGroup;
+    static_assert(G <= R / 2, "a group must fit in the ring twice");
+    const int lane = lane_id(), s0 = lane * K, n = 2 * L + 1, dir = FWD ? 0 : 1;
+    const __amdgpu_buffer_rsrc_t orsrc = lattice_rsrc((FWD ? p.al : p.be) + (int64_t)b * p.T * p.NSP, p.T, p.NSP);
+    int *prog = p.sync + kSyncHead + (dir * p.Bp + b) * kProgPitch;
+    const float *ring = f.ring(dir) + s0;
+    const int *loaded = f.flags + 4 * dir;
+    int *consumed = f.flags + 4 * dir + 3;
+    bool skip[K], valid[K], starved = false;
+    blank_state_flags<K, FWD>(p, b, n, skip, valid);
+    // rows <= last of the step order are in the ring: loader j has then finished (last - j)/kLoaders + 1 rows
+    int have[kLoaders] = {};
+    unsigned long long waited = 0, polls = 0;                // (diagnostics)
+    auto need_rows = [&](int last) {
+#pragma unroll
+        for (int j = 0; j < kLoaders; ++j) {
+            const int need = last >= j ? (last - j) / kLoaders + 1 : 0;
+            if (need > have[j]) {
+                const unsigned long long t0 = (p.debug & 128) ? __builtin_amdgcn_s_memtime() : 0;
+                if (!lds_wait_ge(p, loaded + j, need, have[j])) starved = true;
+                if (p.debug & 128) { waited += __builtin_amdgcn_s_memtime() - t0; ++polls; }
+            }
+        }
+    };
+    auto em_row = [&](float (&dst)[K], int i) {
+        lds_get<K>(ring + (i & (R - 1)) * p.NSP, dst);
+    };
+    auto store = [&](int i, const float (&e)[K]) {
+        const int off = ((FWD ? i : Tb - 1 - i) * p.NSP + s0) * (int)sizeof(float);
+        if (FWD) {
+            agent_store_row<K>(orsrc, off, a);
+        } else {
+            float v[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[k] = a[k] - e[k];
+            agent_store_row<K>(orsrc, off, v);
+        }
+    };
+    {
+        need_rows(0);
+        float e0[K];
+        em_row(e0, 0);
+        blank_first<K, FWD>(a, e0, n);
+        store(0, e0);
+    }
+    int i = 1;
+    for (; i + G <= Tb; i += G) {
+        if (FWD && b == 0 && (i - 1) % 256 == 0) bstamp(p, 1 + (i - 1) / 256);
+        need_rows(i + G - 1);
+        float e[G][K];
+#pragma unroll
+        for (int j = 0; j < G; ++j) em_row(e[j], i + j);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            blank_step<K, FWD>(a, e[j], skip);
+            store(i + j, e[j]);
+        }
+        if (lane == 0) wg_store(consumed, i + G);            // the loaders may refill these slots
+        // Only stores go through this wave's vector-memory counter, it retires in order, and a step
+        // issues at least one: at most kLandLag outstanding => the rows of the steps before
+        // i + G - kLandLag have landed.  (Draining to zero would put the store latency on the chain.)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLandLag) : "memory");
+        if (lane == 0 && i + G > kLandLag) agent_store(prog, i + G - kLandLag);
+    }
+    if (i < Tb) {
+        need_rows(Tb - 1);
+        for (; i < Tb; ++i) {
+            float e[K];
+            em_row(e, i);
+            blank_step<K, FWD>(a, e, skip);
+            store(i, e);
+        }
+    }
+    if (lane == 0) wg_store(consumed, Tb + R);               // (nothing left to protect)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (FWD && b == 0) bstamp(p, 10);
+    if (FWD && b == 0 && (p.debug & 128) && lane == 0) {
+        reinterpret_cast<unsigned long long *>(p.counter)[8 + 16] = waited;
+        reinterpret_cast<unsigned long long *>(p.counter)[8 + 17] = polls;
+    }
+    if (lane == 0) agent_store(prog, starved ? -1 : Tb);     // (a starved chain never releases its rows)
+    if (starved) a[0] = __builtin_nanf("");
+    if (lane == 0) __hip_atomic_fetch_add(p.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // chains finished (of 2 B)
+}
+
+// likelihood of sample b from the last alpha row, and the batch mean
+template <int K>
+__device__ __forceinline__ void blank_publish(const BlankParams &p, int b, bool ok, int Tb, int L, const float (&a)[K])
+{
+    const int n = 2 * L + 1;
+    float nll = __builtin_inff();
+    if (ok && Tb > 0) {
+        float v1 = 0.f, v2 = 0.f;                            // alpha_{T-1}(n-1), alpha_{T-1}(n-2)
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int s = lane_id() * K + k;
+            if (s == n - 1) v1 = a[k];
+            if (s == n - 2) v2 = a[k];
+            bad = bad || a[k] != a[k];
+        }
+        v1 = wave_sum(v1);
+        v2 = n >= 2 ? wave_sum(v2) : kNegB;
+        const float ll2 = lse2_2(v1, v2);
+        nll = ll2 < -1.0e29f ? __builtin_inff() : -ll2 * kLn2;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) nll = __builtin_nanf("");   // (fused: a wait ran out)
+    } else if (ok && L == 0) {
+        nll = 0.f;                                           // empty input, empty target
+    }
+    publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
+                       [&](float v, int i) {
+                           const int64_t Li = p.tgt_len[i];
+                           return v / (float)(Li > 1 ? Li : 1);
+                       });
+}
+
+// three-launch schedule: wave 0 = alpha (+ likelihood and batch mean), wave 1 = beta
 template <int K>
 __global__ __launch_bounds__(128) void blank_chain_kernel(BlankParams p)
 {
     const int b = blockIdx.x, w = wave_id();
     int Tb, L;
     const bool ok = blank_sample_ok(p, b, Tb, L);
-    const int n = 2 * L + 1;
     float a[K];
     if (w == 0) {
-        float nll = __builtin_inff();
-        if (ok && Tb > 0) {
-            blank_chain<K, true>(p, b, Tb, L, a);
-            float v1 = 0.f, v2 = 0.f;                       // alpha_{T-1}(n-1), alpha_{T-1}(n-2)
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int s = lane_id() * K + k;
-                if (s == n - 1) v1 = a[k];
-                if (s == n - 2) v2 = a[k];
-            }
-            v1 = wave_sum(v1);
-            v2 = n >= 2 ? wave_sum(v2) : kNegB;
-            const float ll2 = lse2_2(v1, v2);
-            nll = ll2 < -1.0e29f ? __builtin_inff() : -ll2 * kLn2;
-        } else if (ok && L == 0) {
-            nll = 0.f;                                       // empty input, empty target
-        }
-        publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
-                           [&](float v, int i) {
-                               const int64_t Li = p.tgt_len[i];
-                               return v / (float)(Li > 1 ? Li : 1);
-                           });
+        if (ok && Tb > 0) blank_chain<K, true>(p, b, Tb, L, a);
+        blank_publish<K>(p, b, ok, Tb, L, a);
     } else if (w == 1 && p.grad && ok && Tb > 0) {
         blank_chain<K, false>(p, b, Tb, L, a);
     }
@@ -227,59 +671,116 @@ __global__ __launch_bounds__(128) void blank_chain_kernel(BlankParams p)
 // ---- K2: gamma -> gradient rows ----------------------------------------------------------------
 constexpr int kGradWaves = 4;
 
-constexpr int kMaxV4 = 4;
 
-// One (t,b) row of work for a wave of blank_grad_kernel: everything it loads from HBM.
+// One (t,b) row of work for a wave: everything it loads from HBM.
 template <int K>
 struct BlankRow {
     float4 xr[kMaxV4];
     float al[K], be[K], em[K];
+    int idx = -1;                                            // which row index this buffer holds
     int t, b, Tb, L;
-    bool live;
+    bool live;                                               // false: a zero row (beyond T_b, or no alignment)
+    bool poison;                                             // fused schedule: the wait for the chains ran out
 };
 
-template <int K, bool VEC4>
+// SYNC = false (three launches): idx = t B + b, the lattice is complete.
+// SYNC = true (fused): idx = (2 m + side) B + b names the row at distance m from the FAR end of
+// its sample -- side 0 is t = m (a real row while m >= T_b-1-m, a zero row from T_b on), side 1
+// is t = T_b-1-m (while 0 <= t < m) -- i.e. the rows in the order in which they get both alpha
+// and beta; the loads wait until both chains have published the row; beta comes without its
+// emission, so none is loaded.  r.t < 0: no row here.
+template <int K, bool VEC4, bool SYNC>
 __device__ __forceinline__ void blank_row_load(const BlankParams &p, int idx, BlankRow<K> &r)
 {
     const int lane = lane_id();
-    r.t = idx / p.B;
-    r.b = idx - r.t * p.B;                                   // consecutive waves -> consecutive b: contiguous rows
-    const bool ok = blank_sample_ok(p, r.b, r.Tb, r.L);
-    r.live = ok && r.t < r.Tb && p.nll[r.b] < 3.0e38f;       // beyond T_b, or no alignment: zero row
+    const int q = idx / p.B;
+    r.idx = idx;
+    r.b = __builtin_amdgcn_readfirstlane(idx - q * p.B);     // consecutive waves -> consecutive b: contiguous rows
+    const int2 meta = p.meta[r.b];
+    const int Te = meta.x;                                   // 0 without an alignment: every row is a zero row
+    r.Tb = Te;
+    r.L = meta.y;
+    r.poison = false;
+    if (!SYNC) {
+        r.t = q;
+    } else {
+        const int m = q >> 1;
+        if ((q & 1) == 0) r.t = (m < p.T && (m >= Te || 2 * m >= Te - 1)) ? m : -1;
+        else r.t = (m < Te && Te - 1 - m < m) ? Te - 1 - m : -1;
+        r.t = __builtin_amdgcn_readfirstlane(r.t);
+    }
+    r.live = r.t >= 0 && r.t < Te;
     if (!r.live) return;                                     // wave-uniform
-    const int64_t off = ((int64_t)r.b * p.T + r.t) * p.NSP + lane * K;
+    const int off = (r.t * p.NSP + lane * K) * (int)sizeof(float);
+    if (SYNC) {
+        const int *prog = p.sync + kSyncHead + r.b * kProgPitch;
+        if (!wait_ge(p, prog, r.t + 1) || !wait_ge(p, prog + p.Bp * kProgPitch, Te - r.t)) { r.poison = true; return; }
+        agent_load_row<K>(lattice_rsrc(p.al + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), off, r.al);
+        agent_load_row<K>(lattice_rsrc(p.be + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), off, r.be);
+    }
+    const int64_t o = ((int64_t)r.b * p.T + r.t) * p.NSP + lane * K;
 #pragma unroll
-    for (int k = 0; k < K; ++k) { r.al[k] = p.al[off + k]; r.be[k] = p.be[off + k]; r.em[k] = p.em[off + k]; }
+    for (int k = 0; k < K; ++k) {
+        if (!SYNC) { r.al[k] = p.al[o + k]; r.be[k] = p.be[o + k]; r.em[k] = p.em[o + k]; }
+    }
     if (VEC4) {
         const float *row = p.lp + (int64_t)r.t * p.st + (int64_t)r.b * p.sb;
 #pragma unroll
         for (int i = 0; i < kMaxV4; ++i) {
-            const int q = lane + kWave * i;
-            r.xr[i] = q < (p.C >> 2) ? reinterpret_cast<const float4 *>(row)[q] : make_float4(0, 0, 0, 0);
+            const int q4 = lane + kWave * i;
+            r.xr[i] = q4 < (p.C >> 2) ? reinterpret_cast<const float4 *>(row)[q4] : make_float4(0, 0, 0, 0);
         }
     }
 }
 
-template <int K, bool VEC4>
-__device__ __forceinline__ void blank_row_finish(const BlankParams &p, const BlankRow<K> &r, float *occ, float *gam)
+// The state tables of the sample a wave is working on: this lane's K states in registers, the
+// repeat chain `nxt` in the wave's LDS (walked per row: from global memory every hop was a
+// dependent L2 round trip on the row's critical path).  Reloaded when the sample changes; a
+// wave's stride over the rows is usually a multiple of B, then that is once.
+template <int K>
+struct BlankTables {
+    int b = -1;
+    int cls[K], nxt[K];
+    bool first[K];
+};
+template <int K>
+__device__ __forceinline__ void blank_tables_for(const BlankParams &p, int b, BlankTables<K> &tb, int *nxt_l)
+{
+    if (tb.b == b) return;                                   // wave-uniform
+    tb.b = b;
+    const int s0 = lane_id() * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        tb.cls[k] = p.cls[b * p.NSP + s0 + k];
+        tb.nxt[k] = p.nxt[b * p.NSP + s0 + k];
+        tb.first[k] = p.first[b * p.NSP + s0 + k] != 0;
+        nxt_l[s0 + k] = tb.nxt[k];
+    }
+}
+
+template <int K, bool VEC4, bool SYNC>
+__device__ __forceinline__ void blank_row_finish(const BlankParams &p, const BlankRow<K> &r, float *occ, float *gam, BlankTables<K> &tb)
 {
     const int lane = lane_id(), s0 = lane * K;
+    int *nxt_l = reinterpret_cast<int *>(gam + p.NSP);
+    if (r.t < 0) return;                                     // (fused) this index names no row
     float *g = p.grad + ((int64_t)r.t * p.B + r.b) * p.C;
-    if (!r.live) {
+    if (!r.live || r.poison) {
+        const float z = r.poison ? __builtin_nanf("") : 0.f;
         if (VEC4) {
-            for (int q = lane; q < (p.C >> 2); q += kWave) stream_store(reinterpret_cast<float4 *>(g) + q, make_float4(0, 0, 0, 0));
+            for (int q = lane; q < (p.C >> 2); q += kWave) stream_store(reinterpret_cast<float4 *>(g) + q, make_float4(z, z, z, z));
         } else {
-            for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], 0.f);
+            for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], z);
         }
         return;
     }
     const int n = 2 * r.L + 1;
-    const int *cls = p.cls + r.b * p.NSP, *nxt = p.nxt + r.b * p.NSP, *first = p.first + r.b * p.NSP;
+    blank_tables_for<K>(p, r.b, tb, nxt_l);
     float v[K];
     float m = kNegB;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        v[k] = s0 + k < n ? r.al[k] + r.be[k] - r.em[k] : kNegB;
+        v[k] = s0 + k < n ? (SYNC ? r.al[k] + r.be[k] : r.al[k] + r.be[k] - r.em[k]) : kNegB;
         m = fmaxf(m, v[k]);
     }
     m = wave_max(m);
@@ -299,11 +800,10 @@ __device__ __forceinline__ void blank_row_finish(const BlankParams &p, const Bla
     if (lane == 0) occ[p.blank] = blank_part * inv;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int s = s0 + k;
-        if (first[s]) {                                       // label states only; repeats are chained
-            float tot = gam[s];
-            for (int q = nxt[s]; q >= 0; q = nxt[q]) tot += gam[q];
-            occ[cls[s]] = tot;
+        if (tb.first[k]) {                                    // label states only; repeats are chained
+            float tot = gam[s0 + k];
+            for (int q = tb.nxt[k]; q >= 0; q = nxt_l[q]) tot += gam[q];
+            occ[tb.cls[k]] = tot;
         }
     }
     const float gs = p.grad_scale / (float)(r.L > 1 ? r.L : 1);
@@ -330,35 +830,158 @@ __device__ __forceinline__ void blank_row_finish(const BlankParams &p, const Bla
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int s = s0 + k;
-        if ((s & 1) && s < n) occ[cls[s]] = 0.f;
+        if ((s & 1) && s < n) occ[tb.cls[k]] = 0.f;
     }
 }
 
 // VEC4: C % 4 == 0 and 16-byte aligned rows -> the dense part moves float4 per lane (4x fewer
 // memory instructions).  Rows are double-buffered: the loads of a wave's NEXT row (lattice
 // triples + the whole log-prob row, kMaxV4 float4 per lane cover C <= 1024) are in flight while
-// the current row is reduced and written.
+// the current row is reduced and written.  Wave `first` of `stride` takes rows first, first+stride, ...
+template <int K, bool VEC4, bool SYNC>
+__device__ __forceinline__ void blank_grad_rows(const BlankParams &p, int first, int stride, int total_rows, float *occ, float *gam)
+{
+    int idx = first;
+    if (idx >= total_rows) return;
+    BlankTables<K> tb;
+    if (!SYNC) {
+        BlankRow<K> ra, rb;
+        blank_row_load<K, VEC4, SYNC>(p, idx, ra);
+        for (; idx < total_rows; idx += 2 * stride) {
+            const bool has_b = idx + stride < total_rows;    // wave-uniform
+            if (has_b) blank_row_load<K, VEC4, SYNC>(p, idx + stride, rb);
+            blank_row_finish<K, VEC4, SYNC>(p, ra, occ, gam, tb);
+            if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, ra);
+            if (has_b) blank_row_finish<K, VEC4, SYNC>(p, rb, occ, gam, tb);
+        }
+    } else {
+        // fused launch: two waves per SIMD instead of eight, so each keeps four rows in flight -- but only
+        // one while chains are still running: HBM serves requesters in proportion to what they have in
+        // flight, and the loaders of the chains (the critical path) need most of it until then.
+        BlankRow<K> r0, r1, r2, r3;
+        const int *chains_done = p.sync + 1;
+        bool busy = true;
+        int seen_done = 0;
+#define CTC_TURN(Q, CUR, NEXT)                                                                                 \
+    if (idx + (Q)*stride < total_rows) {                                                                       \
+        if (busy) {                                                                                            \
+            busy = seen_done < 2 * p.B;                      /* (the value read one turn ago) */               \
+            seen_done = agent_load(chains_done);                                                               \
+        }                                                                                                      \
+        if (CUR.idx != idx + (Q)*stride) blank_row_load<K, VEC4, SYNC>(p, idx + (Q)*stride, CUR);              \
+        if (!busy) {                                                                                           \
+            _Pragma("unroll") for (int a = 1; a <= 3; ++a) {                                                   \
+                BlankRow<K> &nb = a == 1 ? nb1(Q) : (a == 2 ? nb2(Q) : NEXT);                                  \
+                const int want = idx + ((Q) + a) * stride;                                                     \
+                if (want < total_rows && nb.idx != want) blank_row_load<K, VEC4, SYNC>(p, want, nb);           \
+            }                                                                                                  \
+        }                                                                                                      \
+        blank_row_finish<K, VEC4, SYNC>(p, CUR, occ, gam, tb);                                                 \
+    }
+        auto nb1 = [&](int q) -> BlankRow<K> & { return q == 0 ? r1 : (q == 1 ? r2 : (q == 2 ? r3 : r0)); };
+        auto nb2 = [&](int q) -> BlankRow<K> & { return q == 0 ? r2 : (q == 1 ? r3 : (q == 2 ? r0 : r1)); };
+        for (; idx < total_rows; idx += 4 * stride) {
+            CTC_TURN(0, r0, r3)
+            CTC_TURN(1, r1, r0)
+            CTC_TURN(2, r2, r1)
+            CTC_TURN(3, r3, r2)
+        }
+#undef CTC_TURN
+    }
+}
+
 template <int K, bool VEC4>
 __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankParams p, int total_rows)
 {
-    extern __shared__ float4 s_buf4[];                       // per wave: occ[C4] + gam[NSP]
+    extern __shared__ float4 s_buf4[];                       // per wave: occ[C4] + gam[NSP] + nxt[NSP]
     const int w = wave_id(), lane = lane_id();
     const int C4 = (p.C + 3) & ~3;
-    float *occ = reinterpret_cast<float *>(s_buf4) + (size_t)w * (C4 + p.NSP);
+    float *occ = reinterpret_cast<float *>(s_buf4) + (size_t)w * (C4 + 2 * p.NSP);
     float *gam = occ + C4;
     for (int c = lane; c < C4; c += kWave) occ[c] = 0.f;
-    const int stride = gridDim.x * kGradWaves;
-    int idx = blockIdx.x * kGradWaves + w;
-    if (idx >= total_rows) return;
-    BlankRow<K> ra, rb;
-    blank_row_load<K, VEC4>(p, idx, ra);
-    for (; idx < total_rows; idx += 2 * stride) {
-        const bool has_b = idx + stride < total_rows;        // wave-uniform
-        if (has_b) blank_row_load<K, VEC4>(p, idx + stride, rb);
-        blank_row_finish<K, VEC4>(p, ra, occ, gam);
-        if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4>(p, idx + 2 * stride, ra);
-        if (has_b) blank_row_finish<K, VEC4>(p, rb, occ, gam);
+    blank_grad_rows<K, VEC4, false>(p, blockIdx.x * kGradWaves + w, gridDim.x * kGradWaves, total_rows, occ, gam);
+}
+
+// ---- fused schedule: the launch -----------------------------------------------------------------
+template <int K, bool VEC4>
+__global__ __launch_bounds__(kFusedWaves * kWave) void blank_fused_kernel(BlankParams p)
+{
+    extern __shared__ float4 s_buf4[];
+    const int w = wave_id(), lane = lane_id();
+    if ((int)blockIdx.x < p.B) {                             // a sample's workgroup (first in dispatch order)
+        const int b = blockIdx.x;
+        const FusedLds f = fused_lds<K>(p, s_buf4);
+        if (threadIdx.x < 16) f.flags[threadIdx.x] = 0;      // (kFusedLdsHead = 64 bytes of flags)
+        __syncthreads();
+        int Tb, L;
+        const bool ok = blank_sample_ok(p, b, Tb, L);
+        const bool run = ok && Tb > 0;
+        float a[K];
+        // waves 0 / 1: the chains; waves 2, 4, 6 / 3, 5, 7: the loaders of the alpha / beta direction
+        if (w == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            if (!run && lane == 0) __hip_atomic_fetch_add(p.sync + 1, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (run) blank_chain_fused<K, true>(p, b, Tb, L, a, f);
+            blank_publish<K>(p, b, ok, Tb, L, a);
+        } else if (w == 1) {
+            __builtin_amdgcn_s_setprio(3);
+            if (run) blank_chain_fused<K, false>(p, b, Tb, L, a, f);
+        } else if (w >= 2 && run) {
+            static_assert(kFusedWaves == 2 + 2 * kLoaders, "two chains and their loaders");
+            const int dir = w & 1, j = (w - 2) >> 1;
+            if (VEC4) {
+                float *stage = f.ring(2) + (w - 2) * 4 * kWave * kMaxV4;
+                blank_loader_rows<K>(p, b, Tb, L, dir, j, f, stage);
+            } else {
+                blank_loader<K>(p, b, Tb, L, dir, j, f);
+            }
+        }
+        return;
     }
+    const int C4 = (p.C + 3) & ~3;                           // a row worker: per wave occ[C4] + gam[NSP] + nxt[NSP]
+    float *occ = reinterpret_cast<float *>(s_buf4) + (size_t)w * (C4 + 2 * p.NSP);
+    float *gam = occ + C4;
+    for (int c = lane; c < C4; c += kWave) occ[c] = 0.f;
+    const int wid = ((int)blockIdx.x - p.B) * kFusedWaves + w, nw = ((int)gridDim.x - p.B) * kFusedWaves;
+    if (wid == 0) bstamp(p, 0);
+    if (wid == nw - 1) bstamp(p, 15);
+    // rows exist from distance (T_b - 1)/2 on (the middle of the sample): start at the smallest one of the batch
+    int m0 = p.T;
+    for (int bb = lane; bb < p.B; bb += kWave) m0 = min(m0, (max(p.meta[bb].x, 1) - 1) >> 1);
+#pragma unroll
+    for (int sh = 1; sh < kWave; sh <<= 1) m0 = min(m0, __shfl_xor(m0, sh));
+    m0 = __builtin_amdgcn_readfirstlane(m0);
+    blank_grad_rows<K, VEC4, true>(p, m0 * 2 * p.B + wid, nw, 2 * p.T * p.B, occ, gam);
+    if (wid == 0) bstamp(p, 12);
+    if (wid == nw - 1) bstamp(p, 13);
+    if (wid == nw / 2) bstamp(p, 14);
+}
+
+static int device_cus()
+{
+    static int cus[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 0;
+    return cus[dev];
+}
+
+// workgroups of blank_fused_kernel that are resident at once on this device (at most one per CU), 0 when unknown
+template <int K, bool VEC4>
+static int fused_capacity(size_t lds)
+{
+    static size_t cached_lds = ~(size_t)0;
+    static int cached = 0;
+    if (cached_lds != lds) {
+        int per_cu = 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(blank_fused_kernel<K, VEC4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blank_fused_kernel<K, VEC4>, kFusedWaves * kWave, lds) != hipSuccess)
+            per_cu = 0;
+        cached = per_cu >= 1 ? device_cus() : 0;
+        cached_lds = lds;
+    }
+    return cached;
 }
 
 template <int K>
@@ -373,18 +996,45 @@ static int run_blank(BlankParams &p, hipStream_t s)
     p.cls = reinterpret_cast<int *>(base + 3 * lattice);
     p.nxt = p.cls + (size_t)p.B * p.NSP;
     p.first = p.nxt + (size_t)p.B * p.NSP;
+    p.meta = reinterpret_cast<int2 *>(p.first + (size_t)p.B * p.NSP);
+    p.Bp = (p.B + 63) & ~63;
+    p.sync = reinterpret_cast<int *>(p.meta + p.Bp);
+    p.nsync = blank_sync_ints(p.T, p.B);
+    static const int debug = getenv("CTC_AMD_BLANK_DEBUG") ? atoi(getenv("CTC_AMD_BLANK_DEBUG")) : 0;
+    p.debug = debug;
+    const size_t row_lds = (((p.C + 3) & ~3) + 2 * p.NSP) * sizeof(float);   // a grad wave's occ[] + gam[] + nxt[]
+    const bool vec4 = (p.C % 4 == 0) && p.C <= 4 * kWave * kMaxV4 && (p.st % 4 == 0) && (p.sb % 4 == 0) &&
+                      (reinterpret_cast<uintptr_t>(p.lp) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.grad) % 16 == 0);
+
+    // fused schedule: long enough for the overlap to pay, every workgroup resident, 32-bit row offsets
+    static const bool no_fused = getenv("CTC_AMD_BLANK_NOFUSED") != nullptr;
+    if (p.grad && !no_fused && p.T >= kFusedMinT && (int64_t)p.T * p.NSP * 4 < ((int64_t)1 << 31) &&
+        (int64_t)2 * p.T * p.B + 4096 < ((int64_t)1 << 31)) {
+        // more than half of a CU's LDS per workgroup: one workgroup per CU, the chains share their SIMDs with nobody
+        size_t lds = kFusedLdsHead + 2 * (size_t)(kRingRows / K) * p.NSP * sizeof(float) +
+                     (vec4 ? 2 * kLoaders * (size_t)(4 * kWave * kMaxV4) * sizeof(float) : 0);   // + a row per loader
+        if (lds < kFusedWaves * row_lds) lds = kFusedWaves * row_lds;
+        if (lds < kMaxLds / 2 + 1024) lds = kMaxLds / 2 + 1024;
+        const int cap = lds <= kMaxLds ? (vec4 ? fused_capacity<K, true>(lds) : fused_capacity<K, false>(lds)) : 0;
+        if (cap >= 2 * p.B && cap - p.B >= 32) {             // at least as many worker workgroups as samples
+            int rc = launch<blank_tables_kernel>(dim3(p.B), dim3(256), p.NSP * sizeof(int), s, p);
+            if (rc) return rc;
+            const dim3 grid(cap), block(kFusedWaves * kWave);
+            if (vec4) return launch<blank_fused_kernel<K, true>>(grid, block, lds, s, p);
+            return launch<blank_fused_kernel<K, false>>(grid, block, lds, s, p);
+        }
+    }
+
     const int rows_per_block = 8;
-    int rc = launch<blank_gather_kernel>(dim3((p.T + rows_per_block - 1) / rows_per_block, p.B), dim3(256),
-                                         p.NSP * sizeof(int), s, p, rows_per_block);
+    const dim3 ggrid((p.T + rows_per_block - 1) / rows_per_block, p.B);
+    int rc = launch<blank_gather_kernel>(ggrid, dim3(256), p.NSP * sizeof(int), s, p, rows_per_block);
     if (rc) return rc;
     rc = launch<blank_chain_kernel<K>>(dim3(p.B), dim3(128), 0, s, p);
     if (rc || !p.grad) return rc;
     const int total = p.T * p.B;
     int blocks = (total + kGradWaves - 1) / kGradWaves;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    const size_t lds = (size_t)kGradWaves * (((p.C + 3) & ~3) + p.NSP) * sizeof(float);
-    const bool vec4 = (p.C % 4 == 0) && p.C <= 4 * kWave * kMaxV4 && (p.st % 4 == 0) && (p.sb % 4 == 0) &&
-                      (reinterpret_cast<uintptr_t>(p.lp) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.grad) % 16 == 0);
+    const size_t lds = kGradWaves * row_lds;
     if (vec4) return launch<blank_grad_kernel<K, true>>(dim3(blocks), dim3(kGradWaves * kWave), lds, s, p, total);
     return launch<blank_grad_kernel<K, false>>(dim3(blocks), dim3(kGradWaves * kWave), lds, s, p, total);
 }
@@ -405,7 +1055,7 @@ extern "C" int ctc_amd_blank_loss_grad(const float *log_probs, int64_t stride_t,
     if (T < 1 || B < 1 || C < 1 || S < 1 || blank < 0 || blank >= C) return CTC_AMD_ERR_BAD_ARGUMENT;
     const int ns = 2 * S + 1;
     if (ns > kWave * 8) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;                 // S <= 255
-    if ((size_t)kGradWaves * (C + 4 + kWave * 8) * sizeof(float) > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    if ((size_t)kGradWaves * (C + 4 + 2 * kWave * 8) * sizeof(float) > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
     BlankParams p;
     p.lp = log_probs; p.st = stride_t; p.sb = stride_b;
     p.tgt = targets; p.tgt64 = targets_i64;

@@ -226,7 +226,9 @@ def test_blank_golden(golden, dev, name):
 
 
 @pytest.mark.parametrize("shape", [(21, 2, 16, 5), (50, 4, 20, 8), (30, 3, 7, 30), (64, 5, 300, 31),
-                                   (90, 3, 40, 63), (120, 2, 50, 64), (200, 2, 1000, 100), (300, 2, 30, 140)])
+                                   (90, 3, 40, 63), (120, 2, 50, 64), (200, 2, 1000, 100), (300, 2, 30, 140),
+                                   (600, 3, 24, 30),      # T >= 128: the fused chains + row-workers launch (blank.hip),
+                                   (1100, 3, 16, 40)])    # here 2 states per lane; 4 and 8 are the two shapes before
 @pytest.mark.parametrize("var_T", [False, True])
 def test_blank_vs_torch_cpu(dev, shape, var_T):
     """the third-party arithmetic itself (torch CPU F.ctc_loss) is the comparator here"""
@@ -243,11 +245,42 @@ def test_blank_vs_torch_cpu(dev, shape, var_T):
     assert len(feasible) >= 1
     fb = np.array(feasible)
     assert (np.abs(r["nll"][fb] - ref["nll"][fb]) <= 1e-5 * np.maximum(1, np.abs(ref["nll"][fb]))).all()
-    assert np.abs(r["grad"][:, fb] - ref["grad"][:, fb]).max() < 2e-6 * max(1.0, 64.0 / B)
+    # (fp32 scans in the log domain: the error of a posterior grows with the length of the sequence)
+    assert np.abs(r["grad"][:, fb] - ref["grad"][:, fb]).max() < 2e-6 * max(1.0, 64.0 / B) * max(1.0, T / 300.0)
     for b in range(B):
         if b not in feasible:
             assert np.isinf(r["nll"][b]) and np.isinf(ref["nll"][b])
             assert np.abs(r["grad"][:, b]).max() == 0.0     # documented: zero, where torch gives NaN
+
+
+def test_blank_fused_schedule_edge_cases(dev):
+    """T >= 128 takes the single persistent launch: ragged lengths, a one-frame sample, an empty target,
+    a sample without any alignment and an empty input in one batch, against the float64 oracle"""
+    import ctc_amd
+    T, B, C, S = 160, 7, 36, 20
+    lp, tgt, Tb, L = synth_blank(77, T, B, C, S, var_T=True)
+    Tb[0], L[0] = T, S
+    Tb[1], L[1] = 1, 1
+    Tb[2], L[2] = T, 0
+    Tb[3], L[3] = 5, 9                                # no alignment: inf, zero gradient
+    Tb[4], L[4] = 0, 0
+    tgt[5, 0:6] = tgt[5, 0]                           # a run of equal labels: blanks forced between them
+    Tb[5], L[5] = T - 3, 8
+    ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64)
+    for targets in (tgt, tgt.int()):
+        r = run_hip(ctc_amd.blank_ctc_loss, lp, targets, Tb, L, dev)
+        fin = np.isfinite(ref["nll"])
+        assert (np.isinf(r["nll"]) == ~fin).all() and not fin[3] and fin.sum() == B - 1
+        assert np.abs(r["nll"][fin] - ref["nll"][fin]).max() <= 1e-5 * max(1.0, np.abs(ref["nll"][fin]).max())
+        assert np.abs(r["grad"][:, fin] - ref["grad"][:, fin]).max() < 2e-6 * 64.0 / B
+        assert np.abs(r["grad"][:, 3]).max() == 0.0 and np.abs(r["grad"][1:, 1]).max() == 0.0
+    # the same rows again through a strided view (the loaders and workers honour the strides)
+    wide = torch.randn(T, B, C + 12)
+    wide[:, :, 4:4 + C] = lp
+    xv = wide.to(dev)[:, :, 4:4 + C].requires_grad_(True)
+    loss, nll = ctc_amd.blank_ctc_loss(xv, tgt.to(dev), Tb.to(dev), L.to(dev))
+    loss.backward()
+    assert np.abs(np_(xv.grad)[:, fin] - ref["grad"][:, fin]).max() < 2e-6 * 64.0 / B
 
 
 def test_blank_int32_targets_and_oracle(dev):

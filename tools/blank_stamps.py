@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Diagnostic: timeline of the fused blank-CTC launch (CTC_AMD_BLANK_DEBUG must include 128).
+Slots: 0 worker 0 enters; 1+k alpha chain of sample 0 at step 256 k; 10 that chain done;
+11 worker 0 done gathering; 12/13/14 worker 0 / last / middle worker done.  Not part of the product path."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+
+wl = bench.Workload("blank", 64, 64, torch.device("cuda:0"), 0)
+ws = wl.new_workspace()
+loss = torch.zeros(4, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+for _ in range(5):
+    wl.fused(loss.data_ptr(), ws, s)
+torch.cuda.synchronize()
+ws[64:256].zero_()
+wl.fused(loss.data_ptr(), ws, s)
+torch.cuda.synchronize()
+st = ws[:256].cpu().numpy()[64:256].view(np.uint64).astype(np.int64)
+t0 = min(v for v in st[:16] if v > 0)
+print("  alpha chain of sample 0: %d waits for emission rows, %d shader clocks in them" % (st[17], st[16]))
+for i, v in enumerate(st[:16]):
+    if v > 0:
+        print("  slot %2d: %8.2f us" % (i, (v - t0) / 100.0))
