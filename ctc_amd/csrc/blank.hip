@@ -49,7 +49,7 @@ constexpr float kNegB = -1.0e30f;    // finite stand-in for -inf inside the scan
 constexpr int kRingRegs = 64;        // three-launch chains: VGPRs of emission rows in flight (64/K rows;
                                      // 8 rows stalled the chain on HBM latency, 16 rows gained 7 %)
 constexpr int kSpinLimit = 1 << 18;  // polls before a wait gives up
-constexpr int kSyncHead = 64;        // ints in front of the counters (status word, chains finished)
+constexpr int kSyncHead = 64;        // ints in front of the counters (status word)
 constexpr int kProgPitch = 32;       // ints between two progress counters: one 128-byte line each (they are polled)
 constexpr int kAuxAgent = 16;        // buffer-instruction cache policy: sc1 = agent scope
 constexpr int kFusedMinT = 128;      // shorter sequences keep the three-launch schedule
@@ -83,7 +83,7 @@ struct BlankParams {
     int *cls, *nxt, *first;          // [B][NSP]: class of state s; next state with the same class;
                                      // 1 when s is the first state carrying its (non-blank) class
     int2 *meta;                      // [B] (T_b, or 0 when there is no alignment: T_b < L_b + adjacent repeats; L_b)
-    // fused schedule: sync[0] status, sync[1] chains finished, sync[kSyncHead + (dir Bp + b) kProgPitch]
+    // fused schedule: sync[0] status, sync[kSyncHead + (dir Bp + b) kProgPitch]
     // steps of chain `dir` of sample b whose lattice rows have landed
     int *sync;
     int Bp, nsync;
@@ -131,6 +131,7 @@ __device__ __forceinline__ bool lds_wait_ge(const BlankParams &p, const int *fla
     for (int it = 0; it < kSpinLimit; ++it) {
         seen = wg_load(flag);
         if (seen >= target) { ok = true; break; }
+        if ((it & 4095) == 4095 && agent_load(p.sync) != 0) break;   // somebody already gave up
         __builtin_amdgcn_s_sleep(1);
     }
     if (!ok) agent_store(p.sync, 1);
@@ -618,7 +619,6 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
     }
     if (lane == 0) agent_store(prog, starved ? -1 : Tb);     // (a starved chain never releases its rows)
     if (starved) a[0] = __builtin_nanf("");
-    if (lane == 0) __hip_atomic_fetch_add(p.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // chains finished (of 2 B)
 }
 
 // likelihood of sample b from the last alpha row, and the batch mean
@@ -677,7 +677,6 @@ template <int K>
 struct BlankRow {
     float4 xr[kMaxV4];
     float al[K], be[K], em[K];
-    int idx = -1;                                            // which row index this buffer holds
     int t, b, Tb, L;
     bool live;                                               // false: a zero row (beyond T_b, or no alignment)
     bool poison;                                             // fused schedule: the wait for the chains ran out
@@ -694,7 +693,6 @@ __device__ __forceinline__ void blank_row_load(const BlankParams &p, int idx, Bl
 {
     const int lane = lane_id();
     const int q = idx / p.B;
-    r.idx = idx;
     r.b = __builtin_amdgcn_readfirstlane(idx - q * p.B);     // consecutive waves -> consecutive b: contiguous rows
     const int2 meta = p.meta[r.b];
     const int Te = meta.x;                                   // 0 without an alignment: every row is a zero row
@@ -855,31 +853,18 @@ __device__ __forceinline__ void blank_grad_rows(const BlankParams &p, int first,
             if (has_b) blank_row_finish<K, VEC4, SYNC>(p, rb, occ, gam, tb);
         }
     } else {
-        // fused launch: two waves per SIMD instead of eight, so each keeps four rows in flight -- but only
-        // one while chains are still running: HBM serves requesters in proportion to what they have in
-        // flight, and the loaders of the chains (the critical path) need most of it until then.
+        // fused launch: two waves per SIMD instead of eight, so each keeps four rows in flight.  (Holding
+        // the workers back to one row while chains are still running, to leave HBM to the loaders, was
+        // slower: 559 against 536 us at config 5.)
         BlankRow<K> r0, r1, r2, r3;
-        const int *chains_done = p.sync + 1;
-        bool busy = true;
-        int seen_done = 0;
+        blank_row_load<K, VEC4, SYNC>(p, idx, r0);
+        if (idx + stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + stride, r1);
+        if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, r2);
 #define CTC_TURN(Q, CUR, NEXT)                                                                                 \
     if (idx + (Q)*stride < total_rows) {                                                                       \
-        if (busy) {                                                                                            \
-            busy = seen_done < 2 * p.B;                      /* (the value read one turn ago) */               \
-            seen_done = agent_load(chains_done);                                                               \
-        }                                                                                                      \
-        if (CUR.idx != idx + (Q)*stride) blank_row_load<K, VEC4, SYNC>(p, idx + (Q)*stride, CUR);              \
-        if (!busy) {                                                                                           \
-            _Pragma("unroll") for (int a = 1; a <= 3; ++a) {                                                   \
-                BlankRow<K> &nb = a == 1 ? nb1(Q) : (a == 2 ? nb2(Q) : NEXT);                                  \
-                const int want = idx + ((Q) + a) * stride;                                                     \
-                if (want < total_rows && nb.idx != want) blank_row_load<K, VEC4, SYNC>(p, want, nb);           \
-            }                                                                                                  \
-        }                                                                                                      \
+        if (idx + ((Q) + 3) * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + ((Q) + 3) * stride, NEXT); \
         blank_row_finish<K, VEC4, SYNC>(p, CUR, occ, gam, tb);                                                 \
     }
-        auto nb1 = [&](int q) -> BlankRow<K> & { return q == 0 ? r1 : (q == 1 ? r2 : (q == 2 ? r3 : r0)); };
-        auto nb2 = [&](int q) -> BlankRow<K> & { return q == 0 ? r2 : (q == 1 ? r3 : (q == 2 ? r0 : r1)); };
         for (; idx < total_rows; idx += 4 * stride) {
             CTC_TURN(0, r0, r3)
             CTC_TURN(1, r1, r0)
@@ -920,7 +905,6 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void blank_fused_kernel(BlankP
         // waves 0 / 1: the chains; waves 2, 4, 6 / 3, 5, 7: the loaders of the alpha / beta direction
         if (w == 0) {
             __builtin_amdgcn_s_setprio(3);
-            if (!run && lane == 0) __hip_atomic_fetch_add(p.sync + 1, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (run) blank_chain_fused<K, true>(p, b, Tb, L, a, f);
             blank_publish<K>(p, b, ok, Tb, L, a);
         } else if (w == 1) {
