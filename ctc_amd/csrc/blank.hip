@@ -211,15 +211,21 @@ __device__ __forceinline__ void blank_tables(const BlankParams &p, int b, int Tb
 {
     const int n = 2 * L + 1;
     for (int s = threadIdx.x; s < p.NSP; s += blockDim.x) {
-        p.cls[b * p.NSP + s] = s_cls[s];
-        int nx = -1;
-        if (s < n && (s & 1))
-            for (int s2 = s + 2; s2 < n; s2 += 2)
-                if (s_cls[s2] == s_cls[s]) { nx = s2; break; }
+        const int c = s_cls[s];
+        p.cls[b * p.NSP + s] = c;
+        // one pass over the labels, no early exit: the LDS reads are independent (and the same address for
+        // every thread), so they pipeline -- two scans that stop at the first match cost 14 us at L = 100
+        const bool label = s < n && (s & 1);
+        int nx = -1, fi = label ? 1 : 0;
+        if (label) {
+#pragma unroll 8
+            for (int s2 = 1; s2 < n; s2 += 2) {
+                const bool same = s_cls[s2] == c;
+                if (same && s2 < s) fi = 0;
+                if (same && s2 > s && nx < 0) nx = s2;
+            }
+        }
         p.nxt[b * p.NSP + s] = nx;
-        int fi = (s < n && (s & 1)) ? 1 : 0;
-        for (int s2 = 1; fi && s2 < s; s2 += 2)
-            if (s_cls[s2] == s_cls[s]) fi = 0;
         p.first[b * p.NSP + s] = fi;
     }
     if (threadIdx.x == 0) {                                  // an alignment needs one step per label plus a blank
