@@ -283,6 +283,29 @@ def test_blank_fused_schedule_edge_cases(dev):
     assert np.abs(np_(xv.grad)[:, fin] - ref["grad"][:, fin]).max() < 2e-6 * 64.0 / B
 
 
+@pytest.mark.parametrize("shape", [(40, 3, 12, 6), (150, 3, 1300, 12)])   # three launches; persistent launch with rows
+def test_blank_nonzero_blank_index_and_wide_rows(dev, shape):            # too wide for the float4 path (C > 1024)
+    """blank = C-1 instead of 0 (torch CPU as the comparator), targets drawn from the other classes"""
+    import ctc_amd
+    T, B, C, S = shape
+    lp, tgt, Tb, L = synth_blank(11 + T, T, B, C, S, var_T=True)
+    blank = C - 1
+    tgt = (tgt - 1).clamp(min=0)                       # synth_blank draws from 1..C-1: shift to 0..C-2
+    lpc = lp.double().clone().requires_grad_(True)
+    loss = torch.nn.functional.ctc_loss(lpc, tgt, Tb, L, blank=blank, reduction="mean", zero_infinity=True)
+    loss.backward()
+    nll = torch.nn.functional.ctc_loss(lp, tgt, Tb, L, blank=blank, reduction="none")
+    x = lp.to(dev).requires_grad_(True)
+    got, got_nll = ctc_amd.blank_ctc_loss(x, tgt.to(dev), Tb.to(dev), L.to(dev), blank=blank)
+    got.backward()
+    fin = np.isfinite(np_(nll))
+    assert fin.any()
+    assert (np.abs(np_(got_nll)[fin] - np_(nll)[fin]) <= 1e-5 * np.maximum(1, np.abs(np_(nll)[fin]))).all()
+    assert np.abs(np_(x.grad)[:, fin] - np_(lpc.grad)[:, fin]).max() < 2e-6 * 64.0 / B
+    m = ctc_amd.BlankCTC(blank=blank)
+    assert abs(float(m(lp.to(dev), tgt.to(dev), Tb, L)) - float(got)) < 1e-6
+
+
 def test_blank_int32_targets_and_oracle(dev):
     import ctc_amd
     lp, tgt, Tb, L = synth_blank(3, 80, 6, 25, 12, var_T=True)
