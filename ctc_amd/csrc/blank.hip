@@ -20,8 +20,8 @@
 //
 // Two schedules:
 //  * three launches (blank_gather_kernel, blank_chain_kernel, blank_grad_kernel), the chains
-//    alone on 2 B waves while 250 CUs idle -- forward-only calls, short sequences, batches too
-//    large for the second schedule;
+//    alone on 2 B waves while 250 CUs idle -- forward-only calls, and every shape where the
+//    second schedule does not pay (run_blank has the measurements);
 //  * ONE persistent launch (blank_fused_kernel, after the tiny blank_tables_kernel) of one
 //    512-thread workgroup per CU.  Workgroups [0, B) own one sample each: waves 0 / 1 run the
 //    alpha / beta chains and touch nothing but LDS and their write-only lattice rows; four loader
@@ -52,7 +52,7 @@ constexpr int kSpinLimit = 1 << 18;  // polls before a wait gives up
 constexpr int kSyncHead = 64;        // ints in front of the counters (status word)
 constexpr int kProgPitch = 32;       // ints between two progress counters: one 128-byte line each (they are polled)
 constexpr int kAuxAgent = 16;        // buffer-instruction cache policy: sc1 = agent scope
-constexpr int kFusedMinT = 128;      // shorter sequences keep the three-launch schedule
+constexpr int kFusedMinT = 128;      // the persistent launch needs at least this many steps (and pays from twice as many)
 constexpr int kMaxV4 = 4;            // float4 per lane that cover a row of the VEC4 paths (C <= 1024)
 constexpr int kFusedWaves = 8;       // waves of a workgroup of the fused launch
 constexpr int kRingRows = 128;       // x 1/K: emission rows per direction in the LDS ring (32 KB for every K)
@@ -996,9 +996,17 @@ static int run_blank(BlankParams &p, hipStream_t s)
     const bool vec4 = (p.C % 4 == 0) && p.C <= 4 * kWave * kMaxV4 && (p.st % 4 == 0) && (p.sb % 4 == 0) &&
                       (reinterpret_cast<uintptr_t>(p.lp) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.grad) % 16 == 0);
 
-    // fused schedule: long enough for the overlap to pay, every workgroup resident, 32-bit row offsets
-    static const bool no_fused = getenv("CTC_AMD_BLANK_NOFUSED") != nullptr;
-    if (p.grad && !no_fused && p.T >= kFusedMinT && (int64_t)p.T * p.NSP * 4 < ((int64_t)1 << 31) &&
+    // Persistent launch.  Hard conditions: a gradient is wanted, every workgroup resident with at least as
+    // many workers as chains, 32-bit row offsets.  Where it PAYS was measured (tools/blank_sweep.py, T = 1000,
+    // us per call persistent / three launches): B=64 C=1000 S=100 274/305, 64x500x100 207/245, 32x1000x100
+    // 185/211, 48x640x100 200/233, 64x800x200 419/505, 64x200x100 206/213 -- but 16x1000x100 185/174,
+    // 96x1000x100 459/410, 128x1000x100 572/509 (the chains take too many CUs from the workers),
+    // 64x1000x30 227/205, 128x400x60 209/133 (two states per lane: the plain chain kernel is fast),
+    // 32x2000x50 419/299 (rows too wide for the float4 loaders), T = 128..192 equal.  CTC_AMD_BLANK_FUSED=1 / 0
+    // forces / forbids it (tests, measurements).
+    const char *force = getenv("CTC_AMD_BLANK_FUSED");
+    const bool forced = force && force[0] == '1', forbidden = force && force[0] == '0';
+    if (p.grad && !forbidden && p.T >= kFusedMinT && (int64_t)p.T * p.NSP * 4 < ((int64_t)1 << 31) &&
         (int64_t)2 * p.T * p.B + 4096 < ((int64_t)1 << 31)) {
         // more than half of a CU's LDS per workgroup: one workgroup per CU, the chains share their SIMDs with nobody
         size_t lds = kFusedLdsHead + 2 * (size_t)(kRingRows / K) * p.NSP * sizeof(float) +
@@ -1006,7 +1014,9 @@ static int run_blank(BlankParams &p, hipStream_t s)
         if (lds < kFusedWaves * row_lds) lds = kFusedWaves * row_lds;
         if (lds < kMaxLds / 2 + 1024) lds = kMaxLds / 2 + 1024;
         const int cap = lds <= kMaxLds ? (vec4 ? fused_capacity<K, true>(lds) : fused_capacity<K, false>(lds)) : 0;
-        if (cap >= 2 * p.B && cap - p.B >= 32) {             // at least as many worker workgroups as samples
+        const bool pays = K >= 4 && vec4 && p.T >= 2 * kFusedMinT && 8 * p.B >= cap && 4 * p.B <= cap &&
+                          (int64_t)p.B * p.C >= 16384;
+        if (cap >= 2 * p.B && cap - p.B >= 32 && (pays || forced)) {
             int rc = launch<blank_tables_kernel>(dim3(p.B), dim3(256), p.NSP * sizeof(int), s, p);
             if (rc) return rc;
             const dim3 grid(cap), block(kFusedWaves * kWave);

@@ -227,13 +227,21 @@ def test_blank_golden(golden, dev, name):
 
 @pytest.mark.parametrize("shape", [(21, 2, 16, 5), (50, 4, 20, 8), (30, 3, 7, 30), (64, 5, 300, 31),
                                    (90, 3, 40, 63), (120, 2, 50, 64), (200, 2, 1000, 100), (300, 2, 30, 140),
-                                   (600, 3, 24, 30),      # T >= 128: the fused chains + row-workers launch (blank.hip),
-                                   (1100, 3, 16, 40)])    # here 2 states per lane; 4 and 8 are the two shapes before
+                                   (600, 3, 24, 30),      # long sequences; 2 states per lane (4 and 8 are the
+                                   (1100, 3, 16, 40)])    # two shapes before)
 @pytest.mark.parametrize("var_T", [False, True])
-def test_blank_vs_torch_cpu(dev, shape, var_T):
-    """the third-party arithmetic itself (torch CPU F.ctc_loss) is the comparator here"""
+@pytest.mark.parametrize("schedule", ["auto", "persistent"])
+def test_blank_vs_torch_cpu(dev, shape, var_T, schedule, monkeypatch):
+    """the third-party arithmetic itself (torch CPU F.ctc_loss) is the comparator here.  `persistent` forces
+    the single persistent launch of blank.hip (the library picks it by itself only for config-5-like batches)"""
     import ctc_amd
     T, B, C, S = shape
+    if schedule == "persistent":
+        if T < 128:
+            pytest.skip("the persistent launch needs T >= 128")
+        monkeypatch.setenv("CTC_AMD_BLANK_FUSED", "1")
+    else:
+        monkeypatch.delenv("CTC_AMD_BLANK_FUSED", raising=False)
     lp, tgt, Tb, L = synth_blank(sum(shape), T, B, C, S, var_T=var_T)
     if not var_T:
         tgt[0, 1:4] = tgt[0, 0]                   # repeated labels force blanks in between
@@ -253,10 +261,12 @@ def test_blank_vs_torch_cpu(dev, shape, var_T):
             assert np.abs(r["grad"][:, b]).max() == 0.0     # documented: zero, where torch gives NaN
 
 
-def test_blank_fused_schedule_edge_cases(dev):
-    """T >= 128 takes the single persistent launch: ragged lengths, a one-frame sample, an empty target,
-    a sample without any alignment and an empty input in one batch, against the float64 oracle"""
+@pytest.mark.parametrize("schedule", ["1", "0"])
+def test_blank_fused_schedule_edge_cases(dev, schedule, monkeypatch):
+    """the single persistent launch (and the three launches): ragged lengths, a one-frame sample, an empty
+    target, a sample without any alignment and an empty input in one batch, against the float64 oracle"""
     import ctc_amd
+    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", schedule)
     T, B, C, S = 160, 7, 36, 20
     lp, tgt, Tb, L = synth_blank(77, T, B, C, S, var_T=True)
     Tb[0], L[0] = T, S
@@ -284,10 +294,11 @@ def test_blank_fused_schedule_edge_cases(dev):
 
 
 @pytest.mark.parametrize("shape", [(40, 3, 12, 6), (150, 3, 1300, 12)])   # three launches; persistent launch with rows
-def test_blank_nonzero_blank_index_and_wide_rows(dev, shape):            # too wide for the float4 path (C > 1024)
+def test_blank_nonzero_blank_index_and_wide_rows(dev, shape, monkeypatch):  # too wide for the float4 path (C > 1024)
     """blank = C-1 instead of 0 (torch CPU as the comparator), targets drawn from the other classes"""
     import ctc_amd
     T, B, C, S = shape
+    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", "1")
     lp, tgt, Tb, L = synth_blank(11 + T, T, B, C, S, var_T=True)
     blank = C - 1
     tgt = (tgt - 1).clamp(min=0)                       # synth_blank draws from 1..C-1: shift to 0..C-2
@@ -304,6 +315,24 @@ def test_blank_nonzero_blank_index_and_wide_rows(dev, shape):            # too w
     assert np.abs(np_(x.grad)[:, fin] - np_(lpc.grad)[:, fin]).max() < 2e-6 * 64.0 / B
     m = ctc_amd.BlankCTC(blank=blank)
     assert abs(float(m(lp.to(dev), tgt.to(dev), Tb, L)) - float(got)) < 1e-6
+
+
+def test_blank_persistent_launch_is_the_default_for_config5_like_batches(dev, monkeypatch):
+    """B = #CUs/8 .. #CUs/4, 4 states per lane, float4 rows, T >= 256: the library takes the persistent launch by
+    itself; the result must agree with the three launches to rounding and with the float64 oracle"""
+    import ctc_amd
+    T, B, C, S = 260, 32, 512, 100
+    lp, tgt, Tb, L = synth_blank(5, T, B, C, S, var_T=True)
+    ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64, threads=8)
+    monkeypatch.delenv("CTC_AMD_BLANK_FUSED", raising=False)
+    auto = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
+    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", "0")
+    three = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
+    for r in (auto, three):
+        assert (np.abs(r["nll"] - ref["nll"]) <= 1e-5 * np.maximum(1, np.abs(ref["nll"]))).all()
+        assert np.abs(r["grad"] - ref["grad"]).max() < 2e-6 * 64.0 / B
+    d = np.abs(auto["grad"] - three["grad"]).max()
+    assert 0.0 < d < 4e-6       # different schedules (beta is stored without its emission): close, not identical
 
 
 def test_blank_int32_targets_and_oracle(dev):
