@@ -104,25 +104,8 @@ __device__ __forceinline__ bool blank_sample_ok(const BlankParams &p, int b, int
 __device__ __forceinline__ int agent_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void agent_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// true once *flag >= target; false when the bounded wait ran out (status word raised).  The flags
-// count chain steps, so the distance to the target says how long to stay away: a thousand waves
-// polling one cache line flat out would tie up its memory channel.
-__device__ __forceinline__ bool wait_ge(const BlankParams &p, const int *flag, int target)
-{
-    bool ok = false;
-    for (int it = 0; it < kSpinLimit; ++it) {
-        const int v = agent_load(flag);
-        if (v >= target) { ok = true; break; }
-        if (v < 0 || ((it & 255) == 255 && agent_load(p.sync) != 0)) break;   // the producer gave up / somebody did
-        const int naps = max(min(target - v, 64), 24);       // ~ one nap (40 x 64 clocks, 1 us) per 8 missing steps, 3 to 8
-        for (int q = 0; q < naps; q += 8) __builtin_amdgcn_s_sleep(40);
-    }
-    if (!ok) agent_store(p.sync, 1);
-    asm volatile("" ::: "memory");                           // nothing below moves above the poll
-    return ok;
-}
-
-// the same inside a workgroup, on a flag in LDS (another wave of the workgroup bumps it)
+// true once *flag >= target, a flag in LDS that another wave of the workgroup bumps; false when the
+// bounded wait ran out (status word raised)
 __device__ __forceinline__ int wg_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // (`seen`: the last value read, so that the caller only comes back when it needs more)
@@ -695,8 +678,36 @@ struct BlankRow {
 // is t = T_b-1-m (while 0 <= t < m) -- i.e. the rows in the order in which they get both alpha
 // and beta; the loads wait until both chains have published the row; beta comes without its
 // emission, so none is loaded.  r.t < 0: no row here.
+// How far the two chains of a sample were when this wave last looked.  A look is a round trip to memory
+// (two when done one after the other) in front of a row's own loads, and the poll retires behind every
+// load the wave has in flight: with a look per row the worker pool did 310 rows/us.  A wave mostly stays
+// with one sample and the chains run ahead of a busy worker, so most rows need no look at all.
+struct ChainsSeen {
+    int b = -1, fwd = 0, bwd = 0;
+};
+
+// both chains of sample b have landed `need_f` / `need_b` steps; false when the bounded wait ran out
+__device__ __forceinline__ bool wait_chains(const BlankParams &p, int b, int need_f, int need_b, ChainsSeen &ps)
+{
+    if (ps.b != b) { ps.b = b; ps.fwd = ps.bwd = 0; }        // wave-uniform
+    if (ps.fwd >= need_f && ps.bwd >= need_b) return true;
+    const int *pf = p.sync + kSyncHead + b * kProgPitch, *pb = pf + p.Bp * kProgPitch;
+    bool ok = false;
+    for (int it = 0; it < kSpinLimit; ++it) {
+        const int vf = agent_load(pf), vb = agent_load(pb);  // (one round trip for the two)
+        ps.fwd = vf; ps.bwd = vb;
+        if (vf >= need_f && vb >= need_b) { ok = true; break; }
+        if (vf < 0 || vb < 0 || ((it & 255) == 255 && agent_load(p.sync) != 0)) break;   // a chain gave up / somebody did
+        const int naps = max(min(max(need_f - vf, need_b - vb), 64), 24);   // ~ a nap (1 us) per 8 missing steps, 3 to 8
+        for (int q = 0; q < naps; q += 8) __builtin_amdgcn_s_sleep(40);
+    }
+    if (!ok) agent_store(p.sync, 1);
+    asm volatile("" ::: "memory");                           // nothing below moves above the poll
+    return ok;
+}
+
 template <int K, bool VEC4, bool SYNC>
-__device__ __forceinline__ void blank_row_load(const BlankParams &p, int idx, BlankRow<K> &r)
+__device__ __forceinline__ void blank_row_load(const BlankParams &p, int idx, BlankRow<K> &r, ChainsSeen &ps)
 {
     const int lane = lane_id();
     const int q = idx / p.B;
@@ -718,8 +729,7 @@ __device__ __forceinline__ void blank_row_load(const BlankParams &p, int idx, Bl
     if (!r.live) return;                                     // wave-uniform
     const int off = (r.t * p.NSP + lane * K) * (int)sizeof(float);
     if (SYNC) {
-        const int *prog = p.sync + kSyncHead + r.b * kProgPitch;
-        if (!wait_ge(p, prog, r.t + 1) || !wait_ge(p, prog + p.Bp * kProgPitch, Te - r.t)) { r.poison = true; return; }
+        if (!wait_chains(p, r.b, r.t + 1, Te - r.t, ps)) { r.poison = true; return; }
         agent_load_row<K>(lattice_rsrc(p.al + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), off, r.al);
         agent_load_row<K>(lattice_rsrc(p.be + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), off, r.be);
     }
@@ -849,34 +859,40 @@ __device__ __forceinline__ void blank_grad_rows(const BlankParams &p, int first,
     int idx = first;
     if (idx >= total_rows) return;
     BlankTables<K> tb;
+    ChainsSeen ps;
     if (!SYNC) {
         BlankRow<K> ra, rb;
-        blank_row_load<K, VEC4, SYNC>(p, idx, ra);
+        blank_row_load<K, VEC4, SYNC>(p, idx, ra, ps);
         for (; idx < total_rows; idx += 2 * stride) {
             const bool has_b = idx + stride < total_rows;    // wave-uniform
-            if (has_b) blank_row_load<K, VEC4, SYNC>(p, idx + stride, rb);
+            if (has_b) blank_row_load<K, VEC4, SYNC>(p, idx + stride, rb, ps);
             blank_row_finish<K, VEC4, SYNC>(p, ra, occ, gam, tb);
-            if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, ra);
+            if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, ra, ps);
             if (has_b) blank_row_finish<K, VEC4, SYNC>(p, rb, occ, gam, tb);
         }
     } else {
-        // fused launch: two waves per SIMD instead of eight, so each keeps four rows in flight.  (Holding
-        // the workers back to one row while chains are still running, to leave HBM to the loaders, was
-        // slower: 559 against 536 us at config 5.)
-        BlankRow<K> r0, r1, r2, r3;
-        blank_row_load<K, VEC4, SYNC>(p, idx, r0);
-        if (idx + stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + stride, r1);
-        if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, r2);
+        // fused launch: two waves per SIMD instead of eight, so each keeps six rows in flight (four: +3 %).
+        // (Holding the workers back to one row while chains are still running, to leave HBM to the loaders,
+        // was slower: 559 against 536 us at config 5.)
+        BlankRow<K> r0, r1, r2, r3, r4, r5;
+        constexpr int NB = 6;                                // rows in flight
+        blank_row_load<K, VEC4, SYNC>(p, idx, r0, ps);
+        if (idx + stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + stride, r1, ps);
+        if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, r2, ps);
+        if (idx + 3 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 3 * stride, r3, ps);
+        if (idx + 4 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 4 * stride, r4, ps);
 #define CTC_TURN(Q, CUR, NEXT)                                                                                 \
     if (idx + (Q)*stride < total_rows) {                                                                       \
-        if (idx + ((Q) + 3) * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + ((Q) + 3) * stride, NEXT); \
+        if (idx + ((Q) + NB - 1) * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + ((Q) + NB - 1) * stride, NEXT, ps); \
         blank_row_finish<K, VEC4, SYNC>(p, CUR, occ, gam, tb);                                                 \
     }
-        for (; idx < total_rows; idx += 4 * stride) {
-            CTC_TURN(0, r0, r3)
+        for (; idx < total_rows; idx += NB * stride) {
+            CTC_TURN(0, r0, r5)
             CTC_TURN(1, r1, r0)
             CTC_TURN(2, r2, r1)
             CTC_TURN(3, r3, r2)
+            CTC_TURN(4, r4, r3)
+            CTC_TURN(5, r5, r4)
         }
 #undef CTC_TURN
     }
@@ -909,19 +925,21 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void blank_fused_kernel(BlankP
         const bool ok = blank_sample_ok(p, b, Tb, L);
         const bool run = ok && Tb > 0;
         float a[K];
+        static_assert(kFusedWaves == 2 + 2 * kLoaders, "two chains and their loaders");
         // waves 0 / 1: the chains; waves 2, 4, 6 / 3, 5, 7: the loaders of the alpha / beta direction
-        if (w == 0) {
+        const int dir = w & 1, role = w >> 1;                // role 0: chain, 1..kLoaders: loader role-1
+        if (role == 0) {
             __builtin_amdgcn_s_setprio(3);
-            if (run) blank_chain_fused<K, true>(p, b, Tb, L, a, f);
-            blank_publish<K>(p, b, ok, Tb, L, a);
-        } else if (w == 1) {
-            __builtin_amdgcn_s_setprio(3);
-            if (run) blank_chain_fused<K, false>(p, b, Tb, L, a, f);
-        } else if (w >= 2 && run) {
-            static_assert(kFusedWaves == 2 + 2 * kLoaders, "two chains and their loaders");
-            const int dir = w & 1, j = (w - 2) >> 1;
+            if (dir == 0) {
+                if (run) blank_chain_fused<K, true>(p, b, Tb, L, a, f);
+                blank_publish<K>(p, b, ok, Tb, L, a);
+            } else if (run) {
+                blank_chain_fused<K, false>(p, b, Tb, L, a, f);
+            }
+        } else if (run) {
+            const int j = role - 1;
             if (VEC4) {
-                float *stage = f.ring(2) + (w - 2) * 4 * kWave * kMaxV4;
+                float *stage = f.ring(2) + (kLoaders * dir + j) * 4 * kWave * kMaxV4;
                 blank_loader_rows<K>(p, b, Tb, L, dir, j, f, stage);
             } else {
                 blank_loader<K>(p, b, Tb, L, dir, j, f);
