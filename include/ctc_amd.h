@@ -87,6 +87,11 @@ int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_t stride_b,
  *   nll   [B]  out: un-normalised negative log-likelihood (+inf if infeasible)
  *   loss  [1]  out: loss_scale * sum_b nll[b] / max(L_b,1)
  *   grad  [T,B,C] out or NULL: (exp(lp) - occupancy) * grad_scale / max(L_b,1)
+ * Long sequences on batches of #CUs/8..#CUs/4 samples (BASELINE config 5) run as ONE persistent
+ * launch of at most one workgroup per CU in which workgroups wait for each other (bounded: a wait
+ * that runs out poisons nll / grad with NaN instead of hanging).  Kernels of other streams on the
+ * same device can only delay it; the workspace belongs to one call in flight at a time, as for every
+ * entry point.  CTC_AMD_BLANK_FUSED=1 / 0 in the environment forces / forbids that schedule.
  */
 int ctc_amd_blank_loss_grad(const float *log_probs, int64_t stride_t, int64_t stride_b,
                             const void *targets, int targets_i64,
