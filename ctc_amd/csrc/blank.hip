@@ -24,8 +24,8 @@
 //    second schedule does not pay (run_blank has the measurements);
 //  * ONE persistent launch (blank_fused_kernel, after the tiny blank_tables_kernel) of one
 //    512-thread workgroup per CU.  Workgroups [0, B) own one sample each: waves 0 / 1 run the
-//    alpha / beta chains and touch nothing but LDS and their write-only lattice rows; four loader
-//    waves (on the other two SIMDs) gather the emission rows straight from log_probs, dozens of
+//    alpha / beta chains and touch nothing but LDS and their write-only lattice rows; six loader
+//    waves (three per direction) gather the emission rows straight from log_probs, dozens of
 //    rows ahead, into an LDS ring per direction -- the emissions never go to HBM, and no load
 //    latency sits on the chains (beta rows are stored WITHOUT their own emission, so
 //    gamma = alpha + beta' needs no emission either).  All other workgroups are row workers:
@@ -35,7 +35,7 @@
 //    workspace.  Forward progress needs every workgroup resident at once: the grid is at most
 //    one workgroup per CU (the LDS request makes that the occupancy too), and chain workgroups
 //    have the lowest block indices, so they are placed first.  All waits are bounded
-//    (kSpinLimit); a wait that runs out raises the status word and poisons its outputs with NaN.
+//    (about a second); a wait that runs out raises the status word and poisons its outputs with NaN.
 //    Cross-XCD visibility (each XCD has its own L2): lattice rows are written with agent-scope
 //    (sc1, write-through) stores and read with sc1 loads; the counters are agent-scope atomics.
 #include <cstdlib>
@@ -48,7 +48,8 @@ namespace ctc {
 constexpr float kNegB = -1.0e30f;    // finite stand-in for -inf inside the scans
 constexpr int kRingRegs = 64;        // three-launch chains: VGPRs of emission rows in flight (64/K rows;
                                      // 8 rows stalled the chain on HBM latency, 16 rows gained 7 %)
-constexpr int kSpinLimit = 1 << 18;  // polls before a wait gives up
+constexpr int kSpinLimit = 1 << 18;  // looks at a chain's progress (>= 3 us apart: ~1 s) before a worker gives up
+constexpr int kLdsSpinLimit = 1 << 23;   // polls of an LDS flag (~0.1 us apart: ~1 s) before a chain / loader gives up
 constexpr int kSyncHead = 64;        // ints in front of the counters (status word)
 constexpr int kProgPitch = 32;       // ints between two progress counters: one 128-byte line each (they are polled)
 constexpr int kAuxAgent = 16;        // buffer-instruction cache policy: sc1 = agent scope
@@ -104,15 +105,15 @@ __device__ __forceinline__ bool blank_sample_ok(const BlankParams &p, int b, int
 __device__ __forceinline__ int agent_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void agent_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// true once *flag >= target, a flag in LDS that another wave of the workgroup bumps; false when the
-// bounded wait ran out (status word raised)
 __device__ __forceinline__ int wg_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// (`seen`: the last value read, so that the caller only comes back when it needs more)
+// true once *flag >= target, a flag in LDS that another wave of the workgroup bumps; false when the
+// bounded wait ran out (status word raised).  `seen`: the last value read, so that the caller only
+// comes back when it needs more
 __device__ __forceinline__ bool lds_wait_ge(const BlankParams &p, const int *flag, int target, int &seen)
 {
     bool ok = false;
-    for (int it = 0; it < kSpinLimit; ++it) {
+    for (int it = 0; it < kLdsSpinLimit; ++it) {
         seen = wg_load(flag);
         if (seen >= target) { ok = true; break; }
         if ((it & 4095) == 4095 && agent_load(p.sync) != 0) break;   // somebody already gave up
