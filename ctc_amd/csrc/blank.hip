@@ -63,6 +63,7 @@ constexpr int kGroup = 16;           // chain steps between hand-off checks (cap
 constexpr int kLandLag = 16;         // lattice stores that may still be in flight when progress is published (0..24
                                      // measure the same, 48 is 1.5 % slower: the workers hear of rows later)
 constexpr size_t kFusedLdsHead = 64; // bytes of LDS flags in front of the rings
+constexpr int kPastLattice = 1 << 30; // a byte offset beyond any sample's lattice (out-of-range buffer accesses are dropped)
 
 // ints of hand-off state behind the per-sample tables (see BlankParams::sync)
 int blank_sync_ints(int T, int B)
@@ -555,8 +556,11 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
     auto em_row = [&](float (&dst)[K], int i) {
         lds_get<K>(ring + (i & (R - 1)) * p.NSP, dst);
     };
+    // lanes whose K states all lie beyond the sample's n states get an offset past the end of the buffer:
+    // the hardware drops their part of the store (config 5: 13 of 64 lanes, a fifth of the lattice bytes)
+    const int lane_off = s0 < n ? s0 * (int)sizeof(float) : kPastLattice;
     auto store = [&](int i, const float (&e)[K]) {
-        const int off = ((FWD ? i : Tb - 1 - i) * p.NSP + s0) * (int)sizeof(float);
+        const int off = (FWD ? i : Tb - 1 - i) * p.NSP * (int)sizeof(float) + lane_off;
         if (FWD) {
             agent_store_row<K>(orsrc, off, a);
         } else {
@@ -728,7 +732,8 @@ __device__ __forceinline__ void blank_row_load(const BlankParams &p, int idx, Bl
     }
     r.live = r.t >= 0 && r.t < Te;
     if (!r.live) return;                                     // wave-uniform
-    const int off = (r.t * p.NSP + lane * K) * (int)sizeof(float);
+    // (lanes beyond the sample's states: past the end of the buffer, they load nothing and read 0)
+    const int off = r.t * p.NSP * (int)sizeof(float) + (lane * K < 2 * r.L + 1 ? lane * K * (int)sizeof(float) : kPastLattice);
     if (SYNC) {
         if (!wait_chains(p, r.b, r.t + 1, Te - r.t, ps)) { r.poison = true; return; }
         agent_load_row<K>(lattice_rsrc(p.al + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), off, r.al);
@@ -1026,7 +1031,7 @@ static int run_blank(BlankParams &p, hipStream_t s)
     // forces / forbids it (tests, measurements).
     const char *force = getenv("CTC_AMD_BLANK_FUSED");
     const bool forced = force && force[0] == '1', forbidden = force && force[0] == '0';
-    if (p.grad && !forbidden && p.T >= kFusedMinT && (int64_t)p.T * p.NSP * 4 < ((int64_t)1 << 31) &&
+    if (p.grad && !forbidden && p.T >= kFusedMinT && (int64_t)p.T * p.NSP * 4 < kPastLattice &&
         (int64_t)2 * p.T * p.B + 4096 < ((int64_t)1 << 31)) {
         // more than half of a CU's LDS per workgroup: one workgroup per CU, the chains share their SIMDs with nobody
         size_t lds = kFusedLdsHead + 2 * (size_t)(kRingRows / K) * p.NSP * sizeof(float) +
