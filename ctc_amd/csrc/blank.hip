@@ -1023,12 +1023,12 @@ static int run_blank(BlankParams &p, hipStream_t s)
 
     // Persistent launch.  Hard conditions: a gradient is wanted, every workgroup resident with at least as
     // many workers as chains, 32-bit row offsets.  Where it PAYS was measured (tools/blank_sweep.py, T = 1000,
-    // us per call persistent / three launches): B=64 C=1000 S=100 274/305, 64x500x100 207/245, 32x1000x100
-    // 185/211, 48x640x100 200/233, 64x800x200 419/505, 64x200x100 206/213 -- but 16x1000x100 185/174,
-    // 96x1000x100 459/410, 128x1000x100 572/509 (the chains take too many CUs from the workers),
-    // 64x1000x30 227/205, 128x400x60 209/133 (two states per lane: the plain chain kernel is fast),
-    // 32x2000x50 419/299 (rows too wide for the float4 loaders), T = 128..192 equal.  CTC_AMD_BLANK_FUSED=1 / 0
-    // forces / forbids it (tests, measurements).
+    // us per call persistent / three launches): B=64 C=1000 S=100 234/299, 64x500x100 189/243, 32x1000x100
+    // 182/211, 48x640x100 200/232, 64x800x200 368/498, 64x200x100 190/213 -- but 16x1000x100 180/174,
+    // 96x1000x100 425/411 (the chains take too many CUs from the workers), 64x1000x30 196/199, 64x400x30
+    // 145/148, 32x400x30 132/119 (two states per lane: the plain chain kernel is fast), 32x2000x50 373/294
+    // (rows too wide for the float4 loaders); over T at 64x1000x100: 50/53 at 128, 75/84 at 256, 122/150 at
+    // 512.  CTC_AMD_BLANK_FUSED=1 / 0 forces / forbids it (tests, measurements).
     const char *force = getenv("CTC_AMD_BLANK_FUSED");
     const bool forced = force && force[0] == '1', forbidden = force && force[0] == '0';
     if (p.grad && !forbidden && p.T >= kFusedMinT && (int64_t)p.T * p.NSP * 4 < kPastLattice &&
