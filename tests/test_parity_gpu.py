@@ -332,7 +332,10 @@ def test_blank_persistent_launch_is_the_default_for_config5_like_batches(dev, mo
         assert (np.abs(r["nll"] - ref["nll"]) <= 1e-5 * np.maximum(1, np.abs(ref["nll"]))).all()
         assert np.abs(r["grad"] - ref["grad"]).max() < 2e-6 * 64.0 / B
     d = np.abs(auto["grad"] - three["grad"]).max()
-    assert 0.0 < d < 4e-6       # different schedules (beta is stored without its emission): close, not identical
+    assert d < 4e-6
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    if cus // 8 <= B <= cus // 4:                     # (the rule of run_blank, blank.hip)
+        assert d > 0.0          # different schedules (beta is stored without its emission): close, not identical
 
 
 def test_blank_int32_targets_and_oracle(dev):
