@@ -26,6 +26,23 @@ __device__ __forceinline__ void stream_store(float4 *p, float4 v)
     __builtin_nontemporal_store(n, reinterpret_cast<native4 *>(p));
 }
 
+// Write-through store (sc1): the bytes leave the XCD's L2 as they are written.  For a launch whose
+// whole gradient fits in the L2s (B <= #CUs: 24 MB at config 2) a non-temporal store still parks its
+// lines there and the end of the kernel waits for their write-back; tools/micro/rw_phase.hip, B = 256,
+// T = 150, C = 158, read everything then write everything: 9.4 us with 8-byte non-temporal stores,
+// 7.6 us with 8-byte write-through stores (16-byte: 7.8 / 5.8 us).  At B = 2048 (reads and writes of
+// different samples mixing, gradient far beyond L2) non-temporal wins (54 against 79 us).
+typedef float wt_f2 __attribute__((ext_vector_type(2)));
+typedef float wt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void through_store(wt_f2 *p, wt_f2 v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void through_store(wt_f4 *p, wt_f4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 // Publish / consume points of LDS hand-offs between waves of a workgroup.  The hardware
 // completes a wave's LDS operations in order, so no wait is needed -- but the COMPILER must not
 // move a row access across the counter access (float rows and int counters do not alias for
@@ -198,14 +215,45 @@ __device__ __forceinline__ int load_label(const void *p, int is64, int64_t i)
     return static_cast<const int32_t *>(p)[is64 ? 2 * i : i];
 }
 
+// Two int64 values at wave-uniform addresses through the scalar memory path (s_load_dwordx2): issued
+// at construction, waited for in get().  The compiler does not know about the loads in flight, so
+// get() ties the values to the wait (they must not be read before it).
+struct ScalarLengths {
+    unsigned long long a, b;
+    __device__ __forceinline__ ScalarLengths(const int64_t *pa, const int64_t *pb)
+    {
+        asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0" : "=&s"(a), "=&s"(b) : "s"(pa), "s"(pb));
+    }
+    __device__ __forceinline__ void get(int64_t &va, int64_t &vb) const
+    {
+        unsigned long long x = a, y = b;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x), "+s"(y));
+        va = (int64_t)x;
+        vb = (int64_t)y;
+    }
+};
+
 // Diagnostics only (CTC_AMD_DEBUG_STOP = -(wave+1)): that wave of workgroup 0 stamps
 // (s_memtime, s_memrealtime) pairs into workspace bytes [64,256) at phase boundaries
 // (tools/stamps.py reads them).  Never executes in a normal run (p.stop == 0).
 template <typename P>
 __device__ __forceinline__ void stamp(const P &p, int slot)
 {
-    if (p.stop >= 0) return;
+    if (p.stop >= 0 || p.stop <= -100) return;
     if (blockIdx.x == 0 && wave_id() == -p.stop - 1 && lane_id() == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
+        o[0] = __builtin_amdgcn_s_memtime();
+        o[1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// Second diagnostic mode (CTC_AMD_DEBUG_STOP = -100 - wave): that wave of workgroup 0 stamps the steps
+// of the kernel's SETUP instead (the phase stamps stay silent), same slots, same reader.
+template <typename P>
+__device__ __forceinline__ void stamp_setup(const P &p, int slot)
+{
+    if (p.stop > -100) return;
+    if (blockIdx.x == 0 && wave_id() == -p.stop - 100 && lane_id() == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
         o[0] = __builtin_amdgcn_s_memtime();
         o[1] = __builtin_amdgcn_s_memrealtime();
@@ -248,7 +296,9 @@ __device__ __forceinline__ void publish_and_reduce(float value, int b, int B, fl
                                                    unsigned *counter, F per_sample)
 {
     publish_value(value, b, nll);
+#ifndef CTC_X_NOREDUCE
     ticket_and_reduce(B, nll, loss, loss_scale, counter, per_sample);
+#endif
 }
 
 }  // namespace ctc

@@ -475,16 +475,21 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
         const bool aligned = C % 2 == 0 && stride_t % 2 == 0 && stride_b % 2 == 0 &&
                              reinterpret_cast<uintptr_t>(x) % 8 == 0 && reinterpret_cast<uintptr_t>(grad) % 8 == 0;
         const size_t rsmem = r16_smem_bytes(T, p.SP, C);
-        if (!no_r16 && aligned && p.SP <= 31 && rsmem <= kMaxLds && (!dual || force_r16)) {
-            switch ((C + 31) / 32) {
-                case 1: return launch<noblank_r16_kernel<1>>(grid, block, rsmem, s, p);
-                case 2: return launch<noblank_r16_kernel<2>>(grid, block, rsmem, s, p);
-                case 3: return launch<noblank_r16_kernel<3>>(grid, block, rsmem, s, p);
-                case 4: return launch<noblank_r16_kernel<4>>(grid, block, rsmem, s, p);
-                case 5: return launch<noblank_r16_kernel<5>>(grid, block, rsmem, s, p);
-                case 6: return launch<noblank_r16_kernel<6>>(grid, block, rsmem, s, p);
-                case 7: return launch<noblank_r16_kernel<7>>(grid, block, rsmem, s, p);
-                default: return launch<noblank_r16_kernel<8>>(grid, block, rsmem, s, p);
+        int n4 = 0, n2 = 0;
+        if (!no_r16 && aligned && r16_shape(C, n4, n2) && p.SP <= 31 && rsmem <= kMaxLds && (!dual || force_r16)) {
+            switch (4 * n4 + n2) {
+                case 1: return launch<noblank_r16_kernel<0, 1>>(grid, block, rsmem, s, p);
+                case 2: return launch<noblank_r16_kernel<0, 2>>(grid, block, rsmem, s, p);
+                case 4: return launch<noblank_r16_kernel<1, 0>>(grid, block, rsmem, s, p);
+                case 5: return launch<noblank_r16_kernel<1, 1>>(grid, block, rsmem, s, p);
+                case 6: return launch<noblank_r16_kernel<1, 2>>(grid, block, rsmem, s, p);
+                case 8: return launch<noblank_r16_kernel<2, 0>>(grid, block, rsmem, s, p);
+                case 9: return launch<noblank_r16_kernel<2, 1>>(grid, block, rsmem, s, p);
+                case 10: return launch<noblank_r16_kernel<2, 2>>(grid, block, rsmem, s, p);
+                case 12: return launch<noblank_r16_kernel<3, 0>>(grid, block, rsmem, s, p);
+                case 13: return launch<noblank_r16_kernel<3, 1>>(grid, block, rsmem, s, p);
+                case 14: return launch<noblank_r16_kernel<3, 2>>(grid, block, rsmem, s, p);
+                default: return launch<noblank_r16_kernel<4, 0>>(grid, block, rsmem, s, p);
             }
         }
         if (!no_xr && xsmem <= kMaxLds && (!dual || 2 * xsmem <= kMaxLds)) {

@@ -16,9 +16,10 @@
 //   * the emission gather x[t, lab_l] goes through a small LDS staging tile (the four raw rows
 //     are written once, the 4 x S gathered values come back with two ds_read_b32);
 //   * in the gradient pass the same tile becomes the class-occupancy tile: it is zeroed, the
-//     scaled posteriors are scattered into it with LDS float atomics (ds_add_f32, repeated
-//     labels simply add up -- no class tables, no duplicate folding), and read back 8 bytes per
-//     lane next to the resident exp(x - max) values.
+//     scaled posteriors are scattered into it (first occurrences of a class store, the k-th
+//     repetition of a label is added in a k-th plain read-modify-write pass -- LDS float atomics
+//     held the LDS pipeline long enough to slow the chains), and read back 8 bytes per lane next
+//     to the resident exp(x - max) values.
 //
 // About 45 instructions per row instead of ~250.  Needs C even (8-byte aligned rows), C <= 256,
 // S <= 31, T <= 168 and 35 KB more LDS than noblank_xr.hpp (one workgroup per CU).
@@ -49,16 +50,13 @@ __device__ __forceinline__ void row16_allmax(int &v) { asm volatile(CTC_ROW16("v
 // sits at l * TP + kR16Pad + t (8-byte cells) in each of the three arrays.  A chain lane then walks
 // its own row with a compile-time stride, so the loads / stores of an unrolled block of steps use
 // immediate offsets (no address arithmetic per step), and TWO consecutive steps move as ONE 16-byte
-// LDS access (the chain is bound by its LDS instructions, not by its arithmetic): the pad is odd so
-// that the forward pairs (steps 1-2, 3-4, ...) start on 16-byte boundaries; beta_t is stored one
-// cell further (at kR16Pad + 1 + t), which makes a beta step read and write the SAME cell index
-// (it reads the emissions of row t+1 and writes row t), its pairs aligned whenever the alpha pairs
-// of that parity are (one single step is peeled off when T_b is even).  Pitch TP = 2 (mod 4)
-// cells: 16-byte aligned rows, and the lanes of a chain access (4 banks each, stride 2 TP words)
-// fall on different banks.  kR16Pad cells before t = 0 and after t = T-1 of every state row
-// take the chains' prefetch (4 steps ahead) and the last, partly idle group of four steps (up to 3
-// steps past the end); `em` pads are zero.  One spare state row SP: all zeros in `em` (read by
-// the chain lanes that only watch progress counters), scratch in `al` / `be`.
+// LDS access: the pad is odd so that the pairs (rows 1-2, 3-4, ...) start on 16-byte boundaries
+// (the backward chain peels one single step off when T_b is odd, so that its pairs are the same).
+// Pitch TP = 2 (mod 4) cells: 16-byte aligned rows, and the lanes of a chain access (4 banks each,
+// stride 2 TP words) fall on different banks.  kR16Pad cells before t = 0 and after t = T-1 of every
+// state row take the chains' prefetch (4 steps ahead) and the last, partly idle group of four steps
+// (up to 3 steps past the end); `em` pads are zero.  One spare state row SP: all zeros in `em` (read
+// by the chain lanes that only watch progress counters), scratch in `al` / `be`.
 constexpr int kR16Pad = 2 * kPrefetch + 1;                  // odd
 __host__ __device__ inline int r16_pitch(int T)
 {
@@ -78,7 +76,7 @@ struct R16Smem {
         cell_t *lat = reinterpret_cast<cell_t *>(base);
         em = lat + kR16Pad;                                  // -> cell (t = 0, l = 0)
         al = em + (size_t)(SP + 1) * TP;
-        be = al + (size_t)(SP + 1) * TP + 1;                 // beta_t one cell further (see above)
+        be = al + (size_t)(SP + 1) * TP;
         dummy = reinterpret_cast<float *>(lat + (size_t)3 * (SP + 1) * TP);   // write-only spare cells
         cnt = reinterpret_cast<int *>(dummy + 8);
         lab = cnt + 16;
@@ -94,8 +92,19 @@ static size_t r16_smem_bytes(int T, int SP, int C)
            (size_t)kPipeWorkers * 4 * RP * 4;
 }
 
-// alpha (FWD) / beta (!FWD) chain of this kernel: (mantissa, exponent) cells as in xr_chain_sync
-// (noblank_xr.hpp), alpha_t stored with, beta_t without the emission of step t.
+// alpha (FWD) / beta (!FWD) chain of this kernel.  Both directions run the SAME recurrence on
+// (mantissa, exponent) cells,
+//     u_t(l) = p_t(l) * (u_prev(l) + u_prev(l -+ 1)),        u = alpha resp. q = beta * p,
+// i.e. beta is carried WITH the emission of its own step (gamma_t(l) ~ alpha_t(l) q_t(l) / p_t(l), the
+// division is the workers' business).  A step is split into an exponent side that never looks at a
+// mantissa,
+//     kk = max(k, k');  s = p_m 2^(k - kk);  s' = p_m 2^(k' - kk);  k = kk + p_k      (6 VALU)
+// and a mantissa side of two dependent instructions, m = m s + m' s' (multiply + DPP multiply-add):
+// the exponents form a max-plus recurrence of their own that runs ahead of the mantissas inside the
+// wave, so the serial path of a step is two instructions instead of four and the other six fill
+// its issue slots.  The larger term is scaled by p_m in [1, 2), so a mantissa never shrinks and grows
+// at most fourfold per step: one v_frexp renormalisation per block of 16 steps keeps it in range (it
+// is the only place where an exponent depends on a mantissa).
 // Hand-off: a worker publishes its rows in groups of four slots; group g of ALL workers together
 // covers positions [28 g, 28 g + 28) of each half of the sequence, so "rows up to position q are
 // there" is one scalar: the number of groups every worker must have finished.  It changes three
@@ -111,10 +120,9 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     // from a disabled lane is the zero the first / last state needs anyway (bound_ctrl)
     if (lane >= (SP > kPipeWorkers ? SP : kPipeWorkers)) return make_cell(0.f, 0);
     const int lrow = lane < SP ? lane : SP;                  // counter-only lanes: the spare state row
-    // step i = 1..T_b-1 reads the emissions of row tr(i) = FWD ? i : T_b - i and writes row
-    // FWD ? i : T_b - 1 - i -- both at cell index x(i) = FWD ? i : T_b - i of their arrays
+    // step i = 0..T_b-1 works on row x(i) = FWD ? i : T_b - 1 - i: reads its emissions, writes its cells
     const cell_t *erow = sm.em + (size_t)lrow * sm.TP;
-    cell_t *orow = (FWD ? sm.al : sm.be - 1) + (size_t)lrow * sm.TP;   // (be - 1: index x, not t)
+    cell_t *orow = (FWD ? sm.al : sm.be) + (size_t)lrow * sm.TP;
     typedef float pair_t __attribute__((ext_vector_type(4)));           // two cells: (lower, higher) time index
     float m;
     int k;
@@ -125,6 +133,7 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     typedef const volatile __attribute__((address_space(3))) int lds_cvint;
     const int *cp = sm.cnt + (lane < kPipeWorkers ? lane : 0);
     int have = 0;                                            // groups known to be published by every worker
+    bool starved = false;
     auto wait_upto = [&](int i_last) {                       // rows of steps 0..i_last must be published
         const int q = pos0 + (i_last < Tb ? i_last : Tb - 1);
         int ng = q / (2 * kPipeWorkers) + 1;
@@ -132,63 +141,63 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
         if (ng <= have) return;                              // (scalar) nothing new to wait for
         const int need = lane < kPipeWorkers ? 4 * ng : 0;
         int spins = 0;
-        while (__builtin_amdgcn_ballot_w64(*(lds_cvint *)cp < need) != 0 && ++spins < kSpinLimit)
+        while (__builtin_amdgcn_ballot_w64(*(lds_cvint *)cp < need) != 0) {
+            if (++spins >= kSpinLimit) { starved = true; break; }
             __builtin_amdgcn_s_sleep(1);
+        }
         lds_order();
         have = ng;
     };
-    auto merge = [&]() {                                     // (m,k) += neighbour, in the larger exponent
+    auto step = [&](float em_, float ek_) {                  // one time step with emission (em_, ek_)
         const int nk = xr_nb<FWD>(k);
-        const float nm = __builtin_bit_cast(float, xr_nb<FWD>(__builtin_bit_cast(int, m)));
         const int kk = k > nk ? k : nk;
-        m = __builtin_amdgcn_ldexpf(m, k - kk) + __builtin_amdgcn_ldexpf(nm, nk - kk);
-        k = kk;
-    };
-    auto step = [&](float em_, float ek_, bool norm) {       // one time step with emission (em_, ek_)
-        if (FWD) merge();
-        m *= em_;
-        k += __builtin_bit_cast(int, ek_);
-        if (norm) {                                          // mantissa back into [0.5, 1)
-            k += __builtin_amdgcn_frexp_expf(m);
-            m = __builtin_amdgcn_frexp_mantf(m);
-        }
-        if (!FWD) merge();
+        const float s1 = __builtin_amdgcn_ldexpf(em_, k - kk), s2 = __builtin_amdgcn_ldexpf(em_, nk - kk);
+        const float nm = __builtin_bit_cast(float, xr_nb<FWD>(__builtin_bit_cast(int, m)));
+        m = __builtin_fmaf(nm, s2, m * s1);
+        k = kk + __builtin_bit_cast(int, ek_);
     };
     // steps (i, i+1) with the pair of emission cells `e` (lower, higher index); returns the pair to store
-    auto step2 = [&](pair_t e, bool norm_second) {
+    auto step2 = [&](pair_t e) {
         pair_t o;
-        step(FWD ? e.x : e.z, FWD ? e.y : e.w, false);
+        step(FWD ? e.x : e.z, FWD ? e.y : e.w);
         const float m1 = m;
         const int k1 = k;
-        step(FWD ? e.z : e.x, FWD ? e.w : e.y, norm_second);
+        step(FWD ? e.z : e.x, FWD ? e.w : e.y);
         const float k1f = __builtin_bit_cast(float, k1), k2f = __builtin_bit_cast(float, k);
         o.x = FWD ? m1 : m;  o.y = FWD ? k1f : k2f;          // lower index: the earlier step when walking up
         o.z = FWD ? m : m1;  o.w = FWD ? k2f : k1f;
         return o;
     };
+    auto renorm = [&]() {                                    // mantissa back into [0.5, 1)  (0 stays 0)
+        k += __builtin_amdgcn_frexp_expf(m);
+        m = __builtin_amdgcn_frexp_mantf(m);
+    };
 
     int *prog = sm.cnt + kPipeWorkers + (FWD ? 0 : 1);
+#ifdef CTC_X_NOCHAIN
+    *prog = Tb;                                              // experiment: what the launch costs without the chains
+    return make_cell(1.f, kXrBias);
+#endif
+#ifndef CTC_X_NOPRIO
     __builtin_amdgcn_s_setprio(3);                           // the chains are the critical path
+#endif
     wait_upto(kPrefetch + 1);
     int i = 1;
-    if (FWD) {                                               // alpha_0 = p_0(0) on state 0 only
-        const cell_t e0 = erow[0];
-        m = lane == 0 ? e0.x : 0.f;
-        k = lane == 0 ? kXrBias + cell_k(e0) : 0;
-        orow[0] = make_cell(m, k);
-    } else {                                                 // beta_{T_b-1} = 1 on state L-1 only
-        m = lane == L - 1 ? 1.f : 0.f;
-        k = lane == L - 1 ? kXrBias : 0;
-        orow[Tb] = make_cell(m, k);
-        if ((Tb & 1) == 0 && Tb > 1) {                       // align the pairs: one single step (wave-uniform)
-            const cell_t e = erow[Tb - 1];
-            step(e.x, e.y, false);
-            orow[Tb - 1] = make_cell(m, k);
+    {                                                        // step 0: u = p on the start state only
+        const int start = FWD ? 0 : L - 1, x = FWD ? 0 : Tb - 1;
+        const cell_t e0 = erow[x];
+        m = lane == start ? e0.x : 0.f;
+        k = lane == start ? kXrBias + cell_k(e0) : 0;
+        orow[x] = make_cell(m, k);
+        if (!FWD && (Tb & 1) == 1 && Tb > 1) {               // align the pairs: one single step (wave-uniform)
+            const cell_t e = erow[Tb - 2];
+            step(e.x, e.y);
+            orow[Tb - 2] = make_cell(m, k);
             i = 2;
         }
     }
-    // x(i) of the current step, and the lowest cell index of the pair (i, i+1): even by construction
-    const int x0 = FWD ? i : Tb - i;
+    // row of the current step: the lowest (FWD) / highest (!FWD) cell index of the pair (i, i+1)
+    const int x0 = FWD ? i : Tb - 1 - i;
     constexpr int kPairs = kBlockSteps / 2;
     // block-relative bases at the LOWEST address a block touches, so that the unrolled pairs use
     // non-negative immediate offsets in both directions (ds offsets are unsigned).  The reads run
@@ -206,11 +215,19 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
         *prog = i;                                           // steps < i are done (every lane, same value)
         if (have < G) wait_upto(i + kBlockSteps - 1 + kPrefetch);
         if (p.stop < 0) stamp(p, 2 + i / kBlockSteps);       // diagnostic: block starts -> slots 2..10
+        renorm();
 #pragma unroll
         for (int q = 0; q < kPairs; ++q) {
             const pair_t e = ring[q & 1];
+#ifndef CTC_X_NOREAD
             ring[q & 1] = rb[FWD ? q : kPairs - 1 - q];
-            wb[FWD ? q : kPairs - 1 - q] = step2(e, (q & 1) == 1);
+#endif
+#ifdef CTC_X_NOWRITE
+            const pair_t o = step2(e);
+            if (q == kPairs - 1) wb[0] = o;
+#else
+            wb[FWD ? q : kPairs - 1 - q] = step2(e);
+#endif
         }
         rb += D * kPairs;
         wb += D * kPairs;
@@ -218,17 +235,18 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     lds_order();
     *prog = i;
     if (have < G) wait_upto(Tb - 1);
+    renorm();
     // the rest in groups of kPrefetch steps = one revolution of the ring (no guards inside).  The
     // last group may run up to three steps past the end: those read zero pad cells and write pad
     // cells of the output rows, which nobody looks at -- the final state is read back below.
-    static_assert(kPrefetch == 4, "tail groups assume one ring revolution = one renormalisation period");
+    static_assert(kPrefetch == 4, "tail groups assume one ring revolution of two pairs");
     if (!FWD) { rb += kPairs - 2; wb += kPairs - 2; }        // lowest address of a 4-step group
     for (; i < Tb; i += kPrefetch) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const pair_t e = ring[q];
             ring[q] = rb[FWD ? q : 1 - q];
-            wb[FWD ? q : 1 - q] = step2(e, q == 1);
+            wb[FWD ? q : 1 - q] = step2(e);
         }
         rb += D * 2;
         wb += D * 2;
@@ -236,15 +254,144 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     lds_order();
     *prog = Tb;
     __builtin_amdgcn_s_setprio(0);
-    // alpha[T_b-1, L_b-1] from where the chain stored it (the registers may hold overrun steps)
-    return (FWD ? sm.al : sm.be)[(size_t)(L - 1) * sm.TP + (FWD ? Tb - 1 : 0)];
+    // alpha[T_b-1, L_b-1] from where the chain stored it (the registers may hold overrun steps);
+    // a hand-off that ran out of patience poisons the sample instead of returning a plausible number
+    cell_t fin = (FWD ? sm.al : sm.be)[(size_t)(L - 1) * sm.TP + (FWD ? Tb - 1 : 0)];
+    if (starved) fin = make_cell(__builtin_nanf(""), 0);
+    return fin;
 }
 
-template <int CH2>
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef float f4u_t __attribute__((ext_vector_type(4), aligned(8)));   // rows in global memory: 8-byte aligned only
+
+// One lane's share of one row: N4 float4 (columns 64 j + 4 i .. + 3) and then N2 float2 (columns
+// 64 N4 + 32 k + 2 i, + 1), i = position of the lane in its 16-lane DPP row.  16-byte accesses
+// wherever the row allows: a vector memory instruction costs its issue slot whatever it carries
+// (tools/micro/rw_phase.hip: the launch's whole read-then-write traffic takes 7.6 us in 8-byte and
+// 5.8 us in 16-byte pieces), and the same goes for the LDS tile.  Only the LAST chunk can stick out
+// of the row (C even; a float4 last chunk only when C % 4 == 0, see r16_shape).
+template <int N4, int N2>
+struct R16Row {
+    f4_t a[N4 > 0 ? N4 : 1];
+    f2_t c[N2 > 0 ? N2 : 1];
+    static constexpr int kCols = 64 * N4 + 32 * N2;
+    static constexpr bool kLast4 = N2 == 0;                  // the last chunk is a float4
+    __device__ static __forceinline__ int off4(int j, int i16) { return 64 * j + 4 * i16; }
+    __device__ static __forceinline__ int off2(int k, int i16) { return 64 * N4 + 32 * k + 2 * i16; }
+    __device__ static __forceinline__ int off_last(int i16) { return kLast4 ? off4(N4 - 1, i16) : off2(N2 - 1, i16); }
+
+    __device__ __forceinline__ void load(const float *row, int i16, int c_last)
+    {
+#pragma unroll
+        for (int j = 0; j < N4; ++j)
+            a[j] = *reinterpret_cast<const f4u_t *>(row + ((kLast4 && j == N4 - 1) ? c_last : off4(j, i16)));
+#pragma unroll
+        for (int k = 0; k < N2; ++k)
+            c[k] = *reinterpret_cast<const f2_t *>(row + (k == N2 - 1 ? c_last : off2(k, i16)));
+    }
+    // largest element; `maskv` (0 or -inf) is added to the last chunk
+    __device__ __forceinline__ float max(float maskv) const
+    {
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < N4; ++j)
+            m = fmaxf(m, fmaxf(fmaxf(a[j].x, a[j].y), fmaxf(a[j].z, a[j].w)) + ((kLast4 && j == N4 - 1) ? maskv : 0.f));
+#pragma unroll
+        for (int k = 0; k < N2; ++k) m = fmaxf(m, fmaxf(c[k].x, c[k].y) + (k == N2 - 1 ? maskv : 0.f));
+        return m;
+    }
+    // x <- exp2((x + mask) log2e + mb); returns the lane's sum
+    __device__ __forceinline__ float exp_sum(float maskv, float mb)
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < N4; ++j) {
+            const float mk = (kLast4 && j == N4 - 1) ? maskv : 0.f;
+            a[j].x = __builtin_amdgcn_exp2f(__builtin_fmaf(a[j].x + mk, kLog2e, mb));
+            a[j].y = __builtin_amdgcn_exp2f(__builtin_fmaf(a[j].y + mk, kLog2e, mb));
+            a[j].z = __builtin_amdgcn_exp2f(__builtin_fmaf(a[j].z + mk, kLog2e, mb));
+            a[j].w = __builtin_amdgcn_exp2f(__builtin_fmaf(a[j].w + mk, kLog2e, mb));
+            sum += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+        }
+#pragma unroll
+        for (int k = 0; k < N2; ++k) {
+            const float mk = k == N2 - 1 ? maskv : 0.f;
+            c[k].x = __builtin_amdgcn_exp2f(__builtin_fmaf(c[k].x + mk, kLog2e, mb));
+            c[k].y = __builtin_amdgcn_exp2f(__builtin_fmaf(c[k].y + mk, kLog2e, mb));
+            sum += c[k].x + c[k].y;
+        }
+        return sum;
+    }
+    // the lane's columns of a staged row in LDS (`trow` = start of the row in the worker's tile)
+    __device__ __forceinline__ void to_tile(float *trow, int i16) const
+    {
+#pragma unroll
+        for (int j = 0; j < N4; ++j) *reinterpret_cast<f4_t *>(trow + off4(j, i16)) = a[j];
+#pragma unroll
+        for (int k = 0; k < N2; ++k) *reinterpret_cast<f2_t *>(trow + off2(k, i16)) = c[k];
+    }
+    __device__ static __forceinline__ void zero_tile(float *trow, int i16)
+    {
+        const f4_t z4 = {0.f, 0.f, 0.f, 0.f};
+        const f2_t z2 = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < N4; ++j) *reinterpret_cast<f4_t *>(trow + off4(j, i16)) = z4;
+#pragma unroll
+        for (int k = 0; k < N2; ++k) *reinterpret_cast<f2_t *>(trow + off2(k, i16)) = z2;
+    }
+    // grad row = x * rs - occupancy (from the tile), written through; `g` = start of the row in grad
+    __device__ __forceinline__ void store_grad(float *g, const float *trow, int i16, float rs, bool col_ok) const
+    {
+#pragma unroll
+        for (int j = 0; j < N4; ++j) {
+            const f4_t o = *reinterpret_cast<const f4_t *>(trow + off4(j, i16));
+            f4_t v;
+            v.x = __builtin_fmaf(a[j].x, rs, -o.x);
+            v.y = __builtin_fmaf(a[j].y, rs, -o.y);
+            v.z = __builtin_fmaf(a[j].z, rs, -o.z);
+            v.w = __builtin_fmaf(a[j].w, rs, -o.w);
+            if (!(kLast4 && j == N4 - 1) || col_ok) through_store(reinterpret_cast<f4_t *>(g + off4(j, i16)), v);
+        }
+#pragma unroll
+        for (int k = 0; k < N2; ++k) {
+            const f2_t o = *reinterpret_cast<const f2_t *>(trow + off2(k, i16));
+            f2_t v;
+            v.x = __builtin_fmaf(c[k].x, rs, -o.x);
+            v.y = __builtin_fmaf(c[k].y, rs, -o.y);
+            if (k < N2 - 1 || col_ok) through_store(reinterpret_cast<f2_t *>(g + off2(k, i16)), v);
+        }
+    }
+    __device__ static __forceinline__ void store_zero(float *g, int i16, bool col_ok)
+    {
+        const f4_t z4 = {0.f, 0.f, 0.f, 0.f};
+        const f2_t z2 = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < N4; ++j)
+            if (!(kLast4 && j == N4 - 1) || col_ok) through_store(reinterpret_cast<f4_t *>(g + off4(j, i16)), z4);
+#pragma unroll
+        for (int k = 0; k < N2; ++k)
+            if (k < N2 - 1 || col_ok) through_store(reinterpret_cast<f2_t *>(g + off2(k, i16)), z2);
+    }
+};
+
+// chunking of a row of C columns (C even): U = ceil(C / 32) units of 32 columns, taken as float4
+// chunks of two units wherever the last chunk then still ends on a lane boundary
+static bool r16_shape(int C, int &n4, int &n2)
+{
+    if (C < 2 || C > 256 || (C & 1)) return false;
+    const int U = (C + 31) / 32;
+    if (U & 1) { n4 = U / 2; n2 = 1; }
+    else if ((C & 3) == 0) { n4 = U / 2; n2 = 0; }
+    else { n4 = U / 2 - 1; n2 = 2; }
+    return true;
+}
+
+template <int N4, int N2>
 __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams p)
 {
     extern __shared__ float4 smem_raw[];
-    constexpr int RP = 32 * CH2;                             // floats per staged row
+    typedef R16Row<N4, N2> Row;
+    constexpr int RP = Row::kCols;                           // floats per staged row
     constexpr int G = kPipeRows / 4;                         // groups of four rows per worker
     const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, RP);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
@@ -254,6 +401,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 
     if (p.stop == 1) return;                                 // diagnostic: cost of the bare dispatch
     stamp(p, 0);
+    stamp_setup(p, 0);
     auto spread = [&](int which) {                           // diagnostic (stop == -50): entry / exit times of
         if (p.stop != -50 || w != 1 || lane != 0) return;    // the first, middle and last workgroup, wave 1
         const int bid = blockIdx.x, nb = gridDim.x;
@@ -264,58 +412,59 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         o[1] = __builtin_amdgcn_s_memrealtime();
     };
     spread(0);
-    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
-    const int raw_label = tid < p.S ? load_label(p.lab, p.lab64, (int64_t)b * p.S + tid) : 0;
-    // this lane's row in each group, its columns: pairs (32j + 2i, 32j + 2i + 1)
+    // The two lengths come through the SCALAR memory path (uniform address): a vector load here is
+    // followed by a readfirstlane, i.e. a full memory round trip BEFORE the first row load is issued,
+    // and later waits on the row loads degrade to vmcnt(0).
+    const ScalarLengths len(p.in_len + b, p.tgt_len + b);
+    // this lane's row in each group
     int tv[G];
-    f2_t v[G][CH2];
-    const int c_lane = 2 * i16;
-    const bool col_ok = 32 * (CH2 - 1) + c_lane < p.C;       // last pair inside the row (C is even)
-    const int c_last = col_ok ? 32 * (CH2 - 1) + c_lane : p.C - 2;
+    Row v[G];
+    const bool col_ok = Row::off_last(i16) < p.C;            // last chunk inside the row
+    const int c_last = col_ok ? Row::off_last(i16) : p.C - (Row::kLast4 ? 4 : 2);
     if (u >= 0) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             tv[g] = pipe_row(p.T, u, 4 * g + rho);
-            const float *row = row_ptr(p, tv[g] >= 0 ? tv[g] : 0, b);
-#pragma unroll
-            for (int j = 0; j < CH2; ++j)
-                v[g][j] = *reinterpret_cast<const f2_t *>(row + (j < CH2 - 1 ? 32 * j + c_lane : c_last));
+            v[g].load(row_ptr(p, tv[g] >= 0 ? tv[g] : 0, b), i16, c_last);
         }
     }
-    // (LDS initialisation that needs no loaded value goes first: it overlaps the loads' latency)
+    stamp_setup(p, 1);                                       // loads issued
+    int64_t Tb64, L64;
+    len.get(Tb64, L64);
+    stamp_setup(p, 2);                                       // lengths there
+    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
+    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
+    // The labels are wave 0's business alone (S <= 31 < 64), in a branch of its own: a vector load on
+    // the workers' (static) path would make every later wait on their row loads a vmcnt(0).
+    if (w == 0) {
+        int k = 0;
+        if (lane < L) {
+            k = load_label(p.lab, p.lab64, (int64_t)b * p.S + lane) % p.C;
+            if (k < 0) k += p.C;                             // python negative index (NoBlankCTC.py:102)
+        }
+        if (lane < p.SP) sm.lab[lane] = k;
+    }
+    stamp_setup(p, 3);                                       // (wave 0: labels stored)
+    // (LDS initialisation that needs no loaded value: it overlaps the loads' latency)
     const cell_t zero = make_cell(0.f, 0);
     for (int i = tid; i < (p.SP + 1) * sm.TP; i += kThreads) sm.em[i - kR16Pad] = zero;   // pads + spare row
     if (tid < 16) sm.cnt[tid] = 0;
     if (tid < 8) sm.dummy[tid] = 0.f;
-    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
-    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
-    if (tid < p.SP) {
-        int k = 0;
-        if (tid < L) {
-            k = raw_label % p.C;
-            if (k < 0) k += p.C;                             // python negative index (NoBlankCTC.py:102)
-        }
-        sm.lab[tid] = k;
-    }
     // LDS-only barrier: __syncthreads() would also wait for every row load of the wave (s_waitcnt
     // vmcnt(0)), but a worker only needs its first group's rows to start
+    stamp_setup(p, 4);                                       // LDS initialised, at the barrier
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     stamp(p, 1);
+    stamp_setup(p, 5);
     if (p.stop == 2) return;                                 // diagnostic: dispatch + setup (+ loads in flight)
 
     if (Tb == 0) {                                           // no alignment exists: nll = 1e13, zero gradient
         if (w == 0)
             publish_and_reduce(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
         if (u >= 0 && p.grad) {
-            const f2_t zero2 = {0.f, 0.f};
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (tv[g] < 0) continue;
-                float *gp = p.grad + ((int64_t)tv[g] * p.B + b) * p.C + c_lane;
-#pragma unroll
-                for (int j = 0; j < CH2; ++j)
-                    if (j < CH2 - 1 || col_ok) __builtin_nontemporal_store(zero2, reinterpret_cast<f2_t *>(gp + 32 * j));
-            }
+            for (int g = 0; g < G; ++g)
+                if (tv[g] >= 0) Row::store_zero(p.grad + ((int64_t)tv[g] * p.B + b) * p.C, i16, col_ok);
         }
         return;
     }
@@ -323,6 +472,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 
     // ---------------------------------------------------------------- chain waves
     if (u < 0) {
+        __builtin_amdgcn_s_setprio(3);                       // the chains are the critical path
         if (w == 0) {
             // while the first rows are on their way: occurrence index of every state among equal
             // labels (0 = first).  Repeated labels add up in the workers' occupancy tiles, one
@@ -346,7 +496,8 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             stamp(p, 11);
             // nll = -log alpha[T_b-1, L_b-1] (NoBlankCTC.py:58-68,139)
             const float am = a.x;
-            const float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(cell_k(a) - kXrBias)) * kLn2 : -kNeg;
+            float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(cell_k(a) - kXrBias)) * kLn2 : -kNeg;
+            if (am != am) nll = am;                          // starved hand-off: NaN, not a plausible number
             publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
             if (p.stop == -50 && lane == 0) {                // diagnostic: when the alpha wave (loss ticket) is done
                 const int bid = blockIdx.x, nb = gridDim.x;
@@ -366,14 +517,14 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 
     // ---------------------------------------------------------------- workers
     float *tile = sm.stage + (size_t)u * 4 * RP;             // this worker's staging / occupancy tile
-    float *tile_row = tile + rho * RP + c_lane;              // this lane's pair j lives at tile_row + 32 j
+    float *trow = tile + rho * RP;                           // this lane's row of it
     // states served by this lane in the two passes: l = i16 and l = 16 + i16 (S <= 31)
     int lst[2];
     float *gat[2];                                           // tile address of class lab[l] in this lane's row
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         lst[s] = 16 * s + i16;
-        gat[s] = tile + rho * RP + (lst[s] < p.SP ? sm.lab[lst[s]] : 0);
+        gat[s] = trow + (lst[s] < p.SP ? sm.lab[lst[s]] : 0);
     }
     const bool own[2] = {lst[0] < L, lst[1] < L};
     const float maskv = col_ok ? 0.f : ninf;
@@ -381,32 +532,27 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     float rs[G];                                             // grad_scale / sum_c exp(x - max), 0 for dead rows
 #pragma unroll
     for (int g = 0; g < G; ++g) {                            // P1: extremes first
-        f2_t *x = v[g];
+        // A SIMD serves its waves oldest first, and the chains cannot start before EVERY worker has
+        // published its first group: without this the youngest worker of a SIMD publishes group 0
+        // after the oldest has finished all three (measured: 3.8 against 2.6 us after entry).
+        if (g == 0) __builtin_amdgcn_s_setprio(2);
+        else if (g == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        Row &x = v[g];
         const int t = tv[g];
         const bool live = t >= 0 && t < Tb;
-        float m = fmaxf(x[CH2 - 1].x, x[CH2 - 1].y) + maskv;
-#pragma unroll
-        for (int j = 0; j < CH2 - 1; ++j) m = fmaxf(m, fmaxf(x[j].x, x[j].y));
+        float m = x.max(maskv);
         row16_allmax(m);
+        if (p.stop < 0 && g == 0) stamp(p, 6);               // diagnostic: the first group's rows are there
         // raw rows -> tile, labels' logits back
-#pragma unroll
-        for (int j = 0; j < CH2; ++j) *reinterpret_cast<f2_t *>(tile_row + 32 * j) = x[j];
+        x.to_tile(trow, i16);
         lds_order();
         float xv[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) xv[s] = *gat[s];
         lds_order();
         // the row registers become exp(x - max): P3 needs softmax(x) = that times 1/sum
-        const float mb = -m * kLog2e;
-        x[CH2 - 1].x = __builtin_amdgcn_exp2f(__builtin_fmaf(x[CH2 - 1].x + maskv, kLog2e, mb));
-        x[CH2 - 1].y = __builtin_amdgcn_exp2f(__builtin_fmaf(x[CH2 - 1].y + maskv, kLog2e, mb));
-        float sum = x[CH2 - 1].x + x[CH2 - 1].y;
-#pragma unroll
-        for (int j = 0; j < CH2 - 1; ++j) {
-            x[j].x = __builtin_amdgcn_exp2f(__builtin_fmaf(x[j].x, kLog2e, mb));
-            x[j].y = __builtin_amdgcn_exp2f(__builtin_fmaf(x[j].y, kLog2e, mb));
-            sum += x[j].x + x[j].y;
-        }
+        float sum = x.exp_sum(maskv, -m * kLog2e);
         row16_allsum(sum);
         const float l2sum = __builtin_amdgcn_logf(sum);
         rs[g] = live ? p.grad_scale * __builtin_amdgcn_rcpf(sum) : 0.f;
@@ -421,14 +567,19 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         }
         lds_order();
         sm.cnt[u] = 4 * (g + 1);                             // publishes the four slots (same wave: in order)
+        // nothing of the next group may be scheduled in front of this publication: the chains wait
+        // for it, and the next group's first instruction waits for loads that are still in flight
+        __builtin_amdgcn_sched_barrier(0);
+        if (p.stop < 0) stamp(p, 8 + g);                     // diagnostic: group g published
     }
+    __builtin_amdgcn_s_setprio(0);
     stamp(p, 2);
     if (!p.grad) return;
 
     const int Tlive = Tb;
     const float gsc = p.grad_scale;
+    bool starved = false;
     const cell_t *const zero_r = sm.em + (size_t)p.SP * sm.TP;   // the spare state row of em stays zero
-    const f2_t zero2 = {0.f, 0.f};
 
     // P3: middle-out, one look at the chains' progress per group
 #pragma unroll
@@ -444,9 +595,10 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         }
         if (need_a > 0) {
             int spins = 0;
-            while ((*(lds_cvint *)(sm.cnt + kPipeWorkers) < need_a || *(lds_cvint *)(sm.cnt + kPipeWorkers + 1) < need_b) &&
-                   ++spins < kSpinLimit)
+            while (*(lds_cvint *)(sm.cnt + kPipeWorkers) < need_a || *(lds_cvint *)(sm.cnt + kPipeWorkers + 1) < need_b) {
+                if (++spins >= kSpinLimit) { starved = true; break; }
                 __builtin_amdgcn_s_sleep(8);
+            }
             lds_order();
         }
         if (p.stop < 0) stamp(p, 3 + (G - 1 - g));
@@ -456,20 +608,22 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             occn[1] = own[1] ? sm.occ[lst[1]] : 0;
             max_occ = __builtin_amdgcn_readfirstlane(sm.occ[(p.SP + 3) & ~3]);
         }
-        f2_t *x = v[g];
+        const Row &x = v[g];
         const int t = tv[g];
         const bool live = t >= 0 && t < Tlive;
         // gamma_t(l) = alpha_t(l) beta_t(l) / sum_l' (...): mantissa products, exponents added and
         // shifted by the row's largest
+        // (beta comes with the emission of its own row: q = beta p, see r16_chain)
         float pr[2];
         int ks[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const bool in = live && lst[s] < p.SP;
+            const bool in = live && own[s];
             const int off = lst[s] * sm.TP + t;
             const cell_t a = *(in ? sm.al + off : zero_r), bb = *(in ? sm.be + off : zero_r);
-            pr[s] = a.x * bb.x;
-            ks[s] = cell_k(a) + cell_k(bb);
+            const cell_t e = *(in ? sm.em + off : zero_r);
+            pr[s] = in ? a.x * bb.x * __builtin_amdgcn_rcpf(e.x) : 0.f;
+            ks[s] = cell_k(a) + cell_k(bb) - cell_k(e);
         }
         int km = max(pr[0] > 0.f ? ks[0] : 0, pr[1] > 0.f ? ks[1] : 0);
         row16_allmax(km);
@@ -478,10 +632,10 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         for (int s = 0; s < 2; ++s) z[s] = __builtin_amdgcn_ldexpf(pr[s], ks[s] - km);
         float tot = z[0] + z[1];
         row16_allsum(tot);
-        const float rinv = (live && tot > 0.f) ? gsc * __builtin_amdgcn_rcpf(tot) : 0.f;
+        float rinv = (live && tot > 0.f) ? gsc * __builtin_amdgcn_rcpf(tot) : 0.f;
+        if (starved) rinv = __builtin_nanf("");              // never observed; loud if a hand-off were broken
         // class occupancy of the four rows: zero the tile, scatter the scaled posteriors
-#pragma unroll
-        for (int j = 0; j < CH2; ++j) *reinterpret_cast<f2_t *>(tile_row + 32 * j) = zero2;
+        Row::zero_tile(trow, i16);
         lds_order();
         // (only lanes that own a state write; pass k adds the k-th repetition of a label)
 #pragma unroll
@@ -495,17 +649,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         }
         lds_order();
         // dense rows: grad = softmax(x) * scale - occupancy   (dead rows: scale = occupancy = 0)
-        if (t >= 0) {
-            float *gp = p.grad + ((int64_t)t * p.B + b) * p.C + c_lane;
-#pragma unroll
-            for (int j = 0; j < CH2; ++j) {
-                const f2_t occ = *reinterpret_cast<const f2_t *>(tile_row + 32 * j);
-                f2_t gv;
-                gv.x = __builtin_fmaf(x[j].x, rs[g], -occ.x);
-                gv.y = __builtin_fmaf(x[j].y, rs[g], -occ.y);
-                if (j < CH2 - 1 || col_ok) __builtin_nontemporal_store(gv, reinterpret_cast<f2_t *>(gp + 32 * j));
-            }
-        }
+        if (t >= 0) x.store_grad(p.grad + ((int64_t)t * p.B + b) * p.C, trow, i16, rs[g], col_ok);
         lds_order();
     }
     stamp(p, 7);

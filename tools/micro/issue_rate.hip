@@ -70,6 +70,76 @@ BENCH(xr_step, 11,
       "v_mul_f32 %0, %1, %0\n\t"
       "v_add_u32 %8, %10, %9\n\t"
       "v_add_u32 %12, %12, %9\n\t")
+// the split exponent / mantissa step (noblank_r16.hpp, round 2): compiler order (9 VALU, every
+// instruction right behind the one it depends on), the same hand-interleaved (exponent side of step
+// j+1 between the mantissa instructions of step j), and with the DPP read fused into v_fmac
+BENCH(xr2_seq, 9,
+      "v_max_i32_dpp v20, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_sub_u32 v21, %8, v20\n\t"
+      "v_ldexp_f32 v21, %1, v21\n\t"
+      "v_sub_u32_dpp v22, %8, v20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 v22, %1, v22\n\t"
+      "v_mov_b32_dpp v23, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mul_f32 %0, %0, v21\n\t"
+      "v_fmac_f32 %0, v23, v22\n\t"
+      "v_add_u32 %8, v20, %9\n\t")
+BENCH(xr2_pipe, 18,
+      "v_max_i32_dpp v20, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp v24, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mul_f32 v25, %0, %2\n\t"
+      "v_sub_u32 v21, %8, v20\n\t"
+      "v_add_u32 %10, v20, %9\n\t"
+      "v_sub_u32_dpp v22, %8, v20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %4, %1, v21\n\t"
+      "v_fmac_f32 v25, v24, %3\n\t"
+      "v_ldexp_f32 %5, %1, v22\n\t"
+      "v_max_i32_dpp v20, %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp v24, v25 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mul_f32 %0, v25, %4\n\t"
+      "v_sub_u32 v21, %10, v20\n\t"
+      "v_add_u32 %8, v20, %9\n\t"
+      "v_sub_u32_dpp v22, %10, v20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %2, %1, v21\n\t"
+      "v_fmac_f32 %0, v24, %5\n\t"
+      "v_ldexp_f32 %3, %1, v22\n\t")
+BENCH(xr2_pipe_fused, 16,
+      "v_max_i32_dpp v20, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mul_f32 v25, %0, %2\n\t"
+      "v_sub_u32 v21, %8, v20\n\t"
+      "v_add_u32 %10, v20, %9\n\t"
+      "v_sub_u32_dpp v22, %8, v20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %4, %1, v21\n\t"
+      "v_fmac_f32_dpp v25, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %5, %1, v22\n\t"
+      "v_max_i32_dpp v20, %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mul_f32 %0, v25, %4\n\t"
+      "v_sub_u32 v21, %10, v20\n\t"
+      "v_add_u32 %8, v20, %9\n\t"
+      "v_sub_u32_dpp v22, %10, v20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %2, %1, v21\n\t"
+      "v_fmac_f32_dpp %0, v25, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %3, %1, v22\n\t")
+// the same with the LDS traffic of a pair of steps: one 16-byte read, one 16-byte write
+BENCH(xr2_pipe_fused_lds, 18,
+      "ds_read_b128 v[26:29], %12\n\t"
+      "v_max_i32_dpp v20, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mul_f32 v25, %0, %2\n\t"
+      "v_sub_u32 v21, %8, v20\n\t"
+      "v_add_u32 %10, v20, %9\n\t"
+      "v_sub_u32_dpp v22, %8, v20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %4, %1, v21\n\t"
+      "v_fmac_f32_dpp v25, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %5, %1, v22\n\t"
+      "v_max_i32_dpp v20, %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mul_f32 %0, v25, %4\n\t"
+      "v_sub_u32 v21, %10, v20\n\t"
+      "v_add_u32 %8, v20, %9\n\t"
+      "v_sub_u32_dpp v22, %10, v20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %2, %1, v21\n\t"
+      "v_fmac_f32_dpp %0, v25, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_ldexp_f32 %3, %1, v22\n\t"
+      "ds_write_b128 %12, v[20:23] offset:2048\n\t")
+
 // the log-domain step (8 dependent ops incl. exp/log)
 BENCH(log_step, 8,
       "v_mov_b32_dpp %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -163,7 +233,7 @@ int main()
     std::vector<Entry> es = {E(dep_add), E(indep_add), E(dep_mul), E(dep_ldexp), E(indep_ldexp), E(dep_maxi), E(dep_maxi_dpp),
                              E(dep_mov_dpp), E(dep_mov_dpp_rowshr), E(dep_add_dpp_rowshr), E(dep_add_dpp_waveshr), E(dep_exp),
                              E(indep_exp), E(dep_log), E(dep_frexp), E(dep_fma), E(dep_cndmask), E(lds_read_dep), E(lds_rw_indep),
-                             E(salu_dep), E(salu_valu_mix), E(xr_step), E(log_step), E(lin_step), E(f64_step), E(dep_mul_f64), E(dep_fma_f64),
+                             E(salu_dep), E(salu_valu_mix), E(xr_step), E(xr2_seq), E(xr2_pipe), E(xr2_pipe_fused), E(log_step), E(lin_step), E(f64_step), E(dep_mul_f64), E(dep_fma_f64),
                              E(f64_step_lds), E(lds_rw_b32), E(lds_rw_b128), E(lds_w_idle_same), E(lds_r_idle_same),
                              E(lds_w_distinct), E(lds_r_distinct), EW(lds_w_distinct, 2), EW(lds_w_distinct, 4),
                              EW(lds_r_distinct, 2), EW(lds_rw_indep, 2), EW(lds_rw_indep, 4), EW(lds_rw_indep, 16), EW(dep_add, 2), EW(dep_add, 8),
@@ -178,6 +248,9 @@ int main()
                              {"lds_w_distinct pitch1416 lanes20", lds_w_distinct, 1, 1, 0, 143360, 0, 1416, 20},
                              {"lds_r_distinct pitch1416 lanes20", lds_r_distinct, 1, 1, 0, 143360, 0, 1416, 20},
                              {"lds_rw_indep pitch1416 lanes20", lds_rw_indep, 1, 1, 0, 143360, 0, 1416, 20},
+                             {"xr2_pipe_fused_lds pitch16 lanes64", xr2_pipe_fused_lds, 1, 1, 0, 143360, 0, 16, 64},
+                             {"xr2_pipe_fused_lds pitch1392 lanes20", xr2_pipe_fused_lds, 1, 1, 0, 143360, 0, 1392, 20},
+                             {"xr2_pipe_fused_lds pitch1392 lanes20 16 waves", xr2_pipe_fused_lds, 16, 1, 0, 143360, 0, 1392, 20},
                              E(lds_add_f32_distinct), E(lds_add_f32_same),
                              {"lds_add_f32_distinct lanes20", lds_add_f32_distinct, 1, 1, 0, 16384, 0, 8, 20},
                              {"lds_add_f32_distinct 16 waves", lds_add_f32_distinct, 16, 1, 0, 16384, 0, 8, 0}};
