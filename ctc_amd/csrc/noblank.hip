@@ -592,7 +592,9 @@ extern "C" int ctc_amd_debug_chain_probe(int T, int SP, int waves_alive, int gri
 {
     using namespace ctc;
     NoblankParams p = {};
-    p.T = T; p.SP = SP; p.S = SP; p.B = grid; p.C = 32; p.stop = 0;
+    p.T = T; p.SP = SP; p.S = SP; p.B = grid; p.C = 32;
+    p.stop = -77;                                            // the chains also time their main loop: out[8], out[9]
+    p.counter = reinterpret_cast<unsigned *>(static_cast<unsigned long long *>(out) + 8);
     const size_t smem = r16_smem_bytes(T, SP, 158);
     return launch<r16_chain_probe_kernel>(dim3(grid), dim3(kThreads), smem, static_cast<hipStream_t>(stream), p,
                                           static_cast<unsigned long long *>(out), waves_alive);

@@ -58,11 +58,28 @@ __device__ __forceinline__ void row16_allmax(int &v) { asm volatile(CTC_ROW16("v
 // (up to 3 steps past the end); `em` pads are zero.  One spare state row SP: all zeros in `em` (read
 // by the chain lanes that only watch progress counters), scratch in `al` / `be`.
 constexpr int kR16Pad = 2 * kPrefetch + 1;                  // odd
+#ifndef CTC_R16_BLOCK
+#define CTC_R16_BLOCK 16
+#endif
+constexpr int kR16Block = CTC_R16_BLOCK;                    // chain steps per block (one look at the workers, one renormalisation)
 __host__ __device__ inline int r16_pitch(int T)
 {
     int tp = T + 2 * kR16Pad + 1;
     while ((tp & 3) != 2) ++tp;
     return tp;
+}
+
+// Row of slot k (0..3) of group g of worker u, or -1: positions 28 g + 2 u and 28 g + 2 u + 1 of the
+// front half (k = 0, 2: rows counted from t = 0) and of the back half (k = 1, 3: from t = T-1).  Group g
+// of all workers together covers positions [28 g, 28 g + 28) of both halves, which is all the chains
+// need to know; inside a group the workers' rows sit at DIFFERENT distances from the ends, so that in
+// the gradient pass they become ready one worker after the other while the chains run out (worker 13
+// 26 steps before the end, worker 0 at the end) instead of all fourteen at the very end.
+__device__ __forceinline__ int r16_row(int T, int u, int g, int k)
+{
+    const int H = (T + 1) >> 1, idx = 2 * kPipeWorkers * g + 2 * u + (k >> 1);
+    if ((k & 1) == 0) return idx < H ? idx : -1;
+    return idx < T - H ? T - 1 - idx : -1;
 }
 
 struct R16Smem {
@@ -116,10 +133,12 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     constexpr int G = kPipeRows / 4;
     constexpr int D = FWD ? 1 : -1;
     const int lane = lane_id();
-    // lanes beyond the states (and beyond the 14 progress counters) sit the chain out: a DPP read
-    // from a disabled lane is the zero the first / last state needs anyway (bound_ctrl)
-    if (lane >= (SP > kPipeWorkers ? SP : kPipeWorkers)) return make_cell(0.f, 0);
-    const int lrow = lane < SP ? lane : SP;                  // counter-only lanes: the spare state row
+    // Lanes beyond the states stay ALIVE on the spare state row (zero emissions: no mass ever, and
+    // nothing a real state reads): the same instruction stream runs faster with the whole wave
+    // switched on than with 20 lanes (tools/micro/chain_asm.hip).  A backward lane reads its upper
+    // neighbour, so state SP-1 sees the zero exponent of an idle lane; a forward lane reads its
+    // lower neighbour, so idle lanes only ever copy exponents nobody looks at.
+    const int lrow = lane < SP ? lane : SP;
     // step i = 0..T_b-1 works on row x(i) = FWD ? i : T_b - 1 - i: reads its emissions, writes its cells
     const cell_t *erow = sm.em + (size_t)lrow * sm.TP;
     cell_t *orow = (FWD ? sm.al : sm.be) + (size_t)lrow * sm.TP;
@@ -148,24 +167,59 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
         lds_order();
         have = ng;
     };
-    auto step = [&](float em_, float ek_) {                  // one time step with emission (em_, ek_)
-        const int nk = xr_nb<FWD>(k);
-        const int kk = k > nk ? k : nk;
-        const float s1 = __builtin_amdgcn_ldexpf(em_, k - kk), s2 = __builtin_amdgcn_ldexpf(em_, nk - kk);
-        const float nm = __builtin_bit_cast(float, xr_nb<FWD>(__builtin_bit_cast(int, m)));
-        m = __builtin_fmaf(nm, s2, m * s1);
-        k = kk + __builtin_bit_cast(int, ek_);
+    // One time step with emission (em, ek), hand-ordered: eight VALU instructions, none of which needs a
+    // wait state in front of it -- the new exponent is formed right behind the max, so that the next
+    // step's DPP read of it (and this step's DPP read of the old one) are far enough from their
+    // writers.  An `s_nop` in front of every v_max_i32_dpp (what the compiler makes of the plain C++
+    // form, and what it puts between two asm statements) costs a full issue slot and more
+    // (tools/micro/chain_asm.hip: 43 cycles per step with, 37 without), so a PAIR of steps is one asm
+    // statement.  (`first`: exponent / mantissa were just written by compiler-scheduled code, which
+    // knows nothing of the DPP reads in here: two wait states of our own.)
+#define CTC_R16_STEP_ASM(K, M, EM, EK, K2, T2, DPP)                                                  \
+            "v_max_i32_dpp %[kk], " K ", " K " " DPP "\n\t"                                           \
+            "v_add_u32 " K2 ", %[kk], " EK "\n\t"                                                     \
+            "v_sub_u32 %[d1], " K ", %[kk]\n\t"                                                       \
+            "v_sub_u32_dpp %[d2], " K ", %[kk] " DPP "\n\t"                                           \
+            "v_ldexp_f32 %[d1], " EM ", %[d1]\n\t"                                                    \
+            "v_ldexp_f32 %[d2], " EM ", %[d2]\n\t"                                                    \
+            "v_mul_f32 " T2 ", " M ", %[d1]\n\t"                                                      \
+            "v_fmac_f32_dpp " T2 ", " M ", %[d2] " DPP "\n\t"
+#define CTC_R16_DPP_F "wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define CTC_R16_DPP_B "wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    auto step = [&](float em_, float ek_) {                  // a single step (alignment peel)
+        int kk, k2, d1, d2;
+        float t;
+        if (FWD)
+            asm("s_nop 1\n\t" CTC_R16_STEP_ASM("%[k]", "%[m]", "%[em]", "%[ek]", "%[k2]", "%[t]", CTC_R16_DPP_F)
+                : [kk] "=&v"(kk), [k2] "=&v"(k2), [d1] "=&v"(d1), [d2] "=&v"(d2), [t] "=&v"(t)
+                : [k] "v"(k), [m] "v"(m), [em] "v"(em_), [ek] "v"(ek_));
+        else
+            asm("s_nop 1\n\t" CTC_R16_STEP_ASM("%[k]", "%[m]", "%[em]", "%[ek]", "%[k2]", "%[t]", CTC_R16_DPP_B)
+                : [kk] "=&v"(kk), [k2] "=&v"(k2), [d1] "=&v"(d1), [d2] "=&v"(d2), [t] "=&v"(t)
+                : [k] "v"(k), [m] "v"(m), [em] "v"(em_), [ek] "v"(ek_));
+        m = t;
+        k = k2;
     };
     // steps (i, i+1) with the pair of emission cells `e` (lower, higher index); returns the pair to store
-    auto step2 = [&](pair_t e) {
+    auto step2 = [&](pair_t e, bool first) {
+        const float e1m = FWD ? e.x : e.z, e1k = FWD ? e.y : e.w, e2m = FWD ? e.z : e.x, e2k = FWD ? e.w : e.y;
+        int kk, d1, d2, k1, k2;
+        float m1, m2;
+#define CTC_R16_PAIR(NOP, DPP)                                                                       \
+        asm(NOP CTC_R16_STEP_ASM("%[k]", "%[m]", "%[e1m]", "%[e1k]", "%[k1]", "%[m1]", DPP)           \
+                CTC_R16_STEP_ASM("%[k1]", "%[m1]", "%[e2m]", "%[e2k]", "%[k2]", "%[m2]", DPP)         \
+            : [kk] "=&v"(kk), [d1] "=&v"(d1), [d2] "=&v"(d2), [k1] "=&v"(k1), [k2] "=&v"(k2),        \
+              [m1] "=&v"(m1), [m2] "=&v"(m2)                                                         \
+            : [k] "v"(k), [m] "v"(m), [e1m] "v"(e1m), [e1k] "v"(e1k), [e2m] "v"(e2m), [e2k] "v"(e2k))
+        if (FWD) { if (first) { CTC_R16_PAIR("s_nop 1\n\t", CTC_R16_DPP_F); } else { CTC_R16_PAIR("", CTC_R16_DPP_F); } }
+        else { if (first) { CTC_R16_PAIR("s_nop 1\n\t", CTC_R16_DPP_B); } else { CTC_R16_PAIR("", CTC_R16_DPP_B); } }
+#undef CTC_R16_PAIR
+        m = m2;
+        k = k2;
+        const float k1f = __builtin_bit_cast(float, k1), k2f = __builtin_bit_cast(float, k2);
         pair_t o;
-        step(FWD ? e.x : e.z, FWD ? e.y : e.w);
-        const float m1 = m;
-        const int k1 = k;
-        step(FWD ? e.z : e.x, FWD ? e.w : e.y);
-        const float k1f = __builtin_bit_cast(float, k1), k2f = __builtin_bit_cast(float, k);
-        o.x = FWD ? m1 : m;  o.y = FWD ? k1f : k2f;          // lower index: the earlier step when walking up
-        o.z = FWD ? m : m1;  o.w = FWD ? k2f : k1f;
+        o.x = FWD ? m1 : m2;  o.y = FWD ? k1f : k2f;         // lower index: the earlier step when walking up
+        o.z = FWD ? m2 : m1;  o.w = FWD ? k2f : k1f;
         return o;
     };
     auto renorm = [&]() {                                    // mantissa back into [0.5, 1)  (0 stays 0)
@@ -198,23 +252,24 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     }
     // row of the current step: the lowest (FWD) / highest (!FWD) cell index of the pair (i, i+1)
     const int x0 = FWD ? i : Tb - 1 - i;
-    constexpr int kPairs = kBlockSteps / 2;
+    constexpr int kPairs = kR16Block / 2;
     // block-relative bases at the LOWEST address a block touches, so that the unrolled pairs use
     // non-negative immediate offsets in both directions (ds offsets are unsigned).  The reads run
     // kPrefetch steps (two pairs) ahead of the writes.
-    const pair_t *rb = reinterpret_cast<const pair_t *>(erow + (FWD ? x0 + kPrefetch : x0 - kPrefetch - (kBlockSteps - 1)));
-    pair_t *wb = reinterpret_cast<pair_t *>(orow + (FWD ? x0 : x0 - (kBlockSteps - 1)));
+    const pair_t *rb = reinterpret_cast<const pair_t *>(erow + (FWD ? x0 + kPrefetch : x0 - kPrefetch - (kR16Block - 1)));
+    pair_t *wb = reinterpret_cast<pair_t *>(orow + (FWD ? x0 : x0 - (kR16Block - 1)));
     pair_t ring[2];
     {
         const pair_t *r0 = reinterpret_cast<const pair_t *>(erow + (FWD ? x0 : x0 - 3));
         ring[0] = r0[FWD ? 0 : 1];                           // steps i, i+1
         ring[1] = r0[FWD ? 1 : 0];                           // steps i+2, i+3
     }
-    for (; i + kBlockSteps <= Tb; i += kBlockSteps) {
+    const unsigned long long loop_t0 = p.stop == -77 ? __builtin_amdgcn_s_memtime() : 0;   // (chain probe only)
+    for (; i + kR16Block <= Tb; i += kR16Block) {
         lds_order();
         *prog = i;                                           // steps < i are done (every lane, same value)
-        if (have < G) wait_upto(i + kBlockSteps - 1 + kPrefetch);
-        if (p.stop < 0) stamp(p, 2 + i / kBlockSteps);       // diagnostic: block starts -> slots 2..10
+        if (have < G) wait_upto(i + kR16Block - 1 + kPrefetch);
+        if (p.stop < 0) stamp(p, 2 + i / 16);       // diagnostic: block starts -> slots 2..10
         renorm();
 #pragma unroll
         for (int q = 0; q < kPairs; ++q) {
@@ -223,15 +278,17 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
             ring[q & 1] = rb[FWD ? q : kPairs - 1 - q];
 #endif
 #ifdef CTC_X_NOWRITE
-            const pair_t o = step2(e);
+            const pair_t o = step2(e, q == 0);
             if (q == kPairs - 1) wb[0] = o;
 #else
-            wb[FWD ? q : kPairs - 1 - q] = step2(e);
+            wb[FWD ? q : kPairs - 1 - q] = step2(e, q == 0);
 #endif
         }
         rb += D * kPairs;
         wb += D * kPairs;
     }
+    if (p.stop == -77 && lane == 0)
+        reinterpret_cast<unsigned long long *>(p.counter)[FWD ? 0 : 1] = __builtin_amdgcn_s_memtime() - loop_t0;
     lds_order();
     *prog = i;
     if (have < G) wait_upto(Tb - 1);
@@ -246,7 +303,7 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
         for (int q = 0; q < 2; ++q) {
             const pair_t e = ring[q];
             ring[q] = rb[FWD ? q : 1 - q];
-            wb[FWD ? q : 1 - q] = step2(e);
+            wb[FWD ? q : 1 - q] = step2(e, q == 0);
         }
         rb += D * 2;
         wb += D * 2;
@@ -424,7 +481,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     if (u >= 0) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            tv[g] = pipe_row(p.T, u, 4 * g + rho);
+            tv[g] = r16_row(p.T, u, g, rho);
             v[g].load(row_ptr(p, tv[g] >= 0 ? tv[g] : 0, b), i16, c_last);
         }
     }
@@ -587,7 +644,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         int need_a = 0, need_b = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int tk = pipe_row(p.T, u, 4 * g + k);      // scalar twin of tv[g]
+            const int tk = r16_row(p.T, u, g, k);            // scalar twin of tv[g]
             if (tk >= 0 && tk < Tlive) {
                 need_a = max(need_a, tk + 1);
                 need_b = max(need_b, Tlive - tk);

@@ -22,5 +22,6 @@ for waves, grid in ((1, 1), (2, 1), (16, 1), (1, 256), (2, 256), (16, 256)):
         assert rc == 0, rc
         torch.cuda.synchronize()
     o = out.cpu().tolist()
-    print("waves_alive=%2d grid=%3d: alpha %6d cyc (%5.1f/step)  beta %6d cyc (%5.1f/step)"
-          % (waves, grid, o[0], o[0] / (T - 1), o[1], o[1] / (T - 1)))
+    nloop = (T - 1) // 16 * 16
+    print("waves_alive=%2d grid=%3d: alpha %6d cyc (%5.1f/step)  beta %6d cyc (%5.1f/step)   main loop only: %5.1f / %5.1f per step"
+          % (waves, grid, o[0], o[0] / (T - 1), o[1], o[1] / (T - 1), o[8] / nloop, o[9] / nloop))
