@@ -2,6 +2,7 @@
 """Throughput of the CTC loss hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N --steps K --warmup W] [--variant noblank|binary|blank]
+                    [--scaling weak|strong --global-batch B] [--batch B_per_gpu]
 
 A "step" is one pass of the hot path over one batch of synthetic, HBM-resident input:
 loss AND the full input gradient (what `loss = ctc_loss(...); loss.backward()` costs in
@@ -10,10 +11,15 @@ Function issues it: one fused `*_loss_grad` launch plus the `scale_grad` launch 
 backward (upstream gradient 1.0).  Default workload = BASELINE configs[1]:
 NoBlankCTC, B=256 per GPU, T=150, C=158, S<=20, fp32.
 
-N>1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same
-per-GPU batch (weak scaling, global batch 256*N, gradient scale 1/B_global) and the
-per-step loss contributions are summed across ranks with RCCL all-reduce, `--loss-bucket`
-steps per collective (1 = one all-reduce per step).
+N>1 (launched by torch.distributed.run, one rank per GPU, RCCL):
+  --scaling weak   (default) every rank runs the per-GPU batch (256): global batch 256*N;
+  --scaling strong BASELINE configs[3]: ONE global batch (--global-batch, default 2048), seeded
+                   once and sliced -- rank r owns shard_bounds(B, r, N); N=1 runs all of it.
+Either way the gradient scale is 1/B_global, there is no gradient communication, and the
+per-step loss contributions are summed with ONE all-reduce per step (`--loss-bucket 1`, the
+default for N>1: eager launches, the collective asynchronous behind the step's kernels);
+`--loss-bucket M` amortises one all-reduce over M graph-replayed steps and is reported as
+the secondary figure `bucketed` of the default run.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,11 +36,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-WORKLOADS = {                  # variant -> (name, T, C, S, default per-GPU batch)
-    "noblank": ("NoBlankCTC B=256 T=150 C=158 S<=20 fp32 (BASELINE configs[1])", 150, 158, 20, 256),
-    "binary": ("NoBlankBinaryCTC B=256 T=150 C=158 S<=20 fp32 (BASELINE configs[2])", 150, 158, 20, 256),
-    "blank": ("blank-CTC B=64 T=2000 C=1000 S=100 fp32 (BASELINE configs[4])", 2000, 1000, 100, 64),
+WORKLOADS = {                  # variant -> (name, T, C, S, default per-GPU batch, BASELINE config)
+    "noblank": ("NoBlankCTC", 150, 158, 20, 256, "configs[1]"),
+    "binary": ("NoBlankBinaryCTC", 150, 158, 20, 256, "configs[2]"),
+    "blank": ("blank-CTC", 2000, 1000, 100, 64, "configs[4]"),
 }
+
+
+def workload_name(variant, B, global_batch=None, world=1, scaling="weak"):
+    name, T, C, S, Bdef, cfg = WORKLOADS[variant]
+    sfx = "S=%d" % S if variant == "blank" else "S<=%d" % S
+    if scaling == "strong":
+        return "%s B=%d (sharded over %d GPU%s) T=%d C=%d %s fp32 (BASELINE configs[3])" % (
+            name, global_batch, world, "" if world == 1 else "s", T, C, sfx)
+    tag = " (BASELINE %s)" % cfg if B == Bdef else " (BASELINE %s shape, batch overridden)" % cfg
+    return "%s B=%d T=%d C=%d %s fp32%s" % (name, B, T, C, sfx, tag)
 
 
 def parse():
@@ -44,11 +60,15 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--variant", default="noblank", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the BASELINE config)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = --batch per GPU; strong = --global-batch sharded over the ranks (BASELINE configs[3])")
+    ap.add_argument("--global-batch", type=int, default=2048, help="--scaling strong: the global batch")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph: steps are replayed from a captured hipGraph; eager: one ctypes call per launch")
     ap.add_argument("--graph-steps", type=int, default=50, help="steps captured per hipGraph")
     ap.add_argument("--loss-bucket", type=int, default=None,
-                    help="N>1: steps per RCCL all-reduce of the loss scalars (default = graph-steps, eager: 1)")
+                    help="N>1: steps per RCCL all-reduce of the loss scalars (default 1 = one all-reduce per step)")
+    ap.add_argument("--no-eager-python", action="store_true", help="skip the secondary CTCLoss.apply + backward() timing")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 collective backend: nccl = RCCL over xGMI; gloo only to rehearse the multi-rank "
                          "path on a box with fewer GPUs than ranks (ranks then share devices)")
@@ -58,23 +78,27 @@ def parse():
 
 
 class Workload:
-    """Device-resident synthetic batch + the C-ABI call sequence of one step."""
+    """Device-resident synthetic batch + the C-ABI call sequence of one step.  `lo:hi` = this rank's
+    slice of a batch of `B_gen` samples generated from `seed` (strong scaling: the global batch)."""
 
-    def __init__(self, variant, B, B_global, dev, seed):
+    def __init__(self, variant, B_gen, B_global, dev, seed, lo=0, hi=None, name=None):
         from ctc_amd import _lib
         from tests import helpers
-        self.variant, self.B, self.dev = variant, B, dev
-        self.name, self.T, self.C, self.S, _ = WORKLOADS[variant]
-        T, C, S = self.T, self.C, self.S
+        hi = B_gen if hi is None else hi
+        self.variant, self.B, self.dev = variant, hi - lo, dev
+        _, self.T, self.C, self.S = WORKLOADS[variant][:4]
+        self.name = name or workload_name(variant, self.B)
+        T, B, C, S = self.T, self.B, self.C, self.S
         if variant == "noblank":
-            x, tg, il, tl = helpers.synth_noblank(seed, T, B, C, S)
+            x, tg, il, tl = helpers.synth_noblank(seed, T, B_gen, C, S)
             self.target_bytes = 4 * B * S
         elif variant == "binary":
-            x, tg, il, tl = helpers.synth_binary(seed, T, B, C, S)
+            x, tg, il, tl = helpers.synth_binary(seed, T, B_gen, C, S)
             self.target_bytes = 4 * B * S * C
         else:
-            x, tg, il, tl = helpers.synth_blank(seed, T, B, C, S)
+            x, tg, il, tl = helpers.synth_blank(seed, T, B_gen, C, S)
             self.target_bytes = 8 * B * S
+        x, tg, il, tl = x[:, lo:hi].contiguous(), tg[lo:hi].contiguous(), il[lo:hi].contiguous(), tl[lo:hi].contiguous()
         self.host = (x, tg, il, tl)
         self.x, self.tg, self.il, self.tl = (t.to(dev) for t in (x, tg, il, tl))
         self.lib = _lib.load()
@@ -148,6 +172,45 @@ def cpu_baseline(wl, budget_s):
             "single_thread_value": round(out["1"][0], 2), "host_cores_visible": ncpu}
 
 
+def torch_cpu_ctc_baseline(wl, budget_s):
+    """torch.nn.functional.ctc_loss on the host cores beside the blank variant."""
+    x, tg, il, tl = wl.host
+    n, t0 = 0, time.perf_counter()
+    while True:
+        xr = x.clone().requires_grad_(True)
+        torch.nn.functional.ctc_loss(xr, tg, il, tl, blank=0, reduction="mean").backward()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": round(wl.B * n / el, 2), "unit": "samples/s", "threads": torch.get_num_threads(),
+            "what": "torch.nn.functional.ctc_loss fwd+bwd on CPU, %d steps of the same batch" % n}
+
+
+def eager_python_step(wl, iters=300):
+    """The step through the Python surface, issued eagerly as the reference's loop does
+    (train.py:427,444): CTCLoss.apply / blank_ctc_loss + loss.backward()."""
+    import ctc_amd
+    from ctc_amd import functional as F
+    x = wl.x.clone().requires_grad_(True)
+
+    def one():
+        x.grad = None
+        if wl.variant == "blank":
+            loss, _ = F.blank_ctc_loss(x, wl.tg, wl.il, wl.tl)
+        else:
+            loss = ctc_amd.CTCLoss.apply(x, wl.tg, wl.il, wl.tl)
+        loss.backward()
+    for _ in range(30):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e6
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -170,33 +233,52 @@ def main():
             dist.init_process_group("gloo")
 
     variant = a.variant
-    B = a.batch or WORKLOADS[variant][4]
     K = a.steps if a.steps is not None else (500 if variant != "blank" else 30)
     W = a.warmup if a.warmup is not None else (50 if variant != "blank" else 5)
-    wl = Workload(variant, B, B * world, dev, seed=rank)
-    M = max(1, min(a.graph_steps, K)) if a.launch == "graph" else 1
-    bucket = a.loss_bucket or M
+    if a.scaling == "strong":
+        from ctc_amd.distributed import shard_bounds
+        Bg = a.global_batch
+        lo, hi = shard_bounds(Bg, rank, world)
+        wl = Workload(variant, Bg, Bg, dev, seed=0, lo=lo, hi=hi,
+                      name=workload_name(variant, hi - lo, Bg, world, "strong"))
+    else:
+        Bl = a.batch or WORKLOADS[variant][4]
+        Bg = Bl * world
+        wl = Workload(variant, Bl, Bg, dev, seed=rank)
+    B = wl.B
+
+    # N>1 default: ONE all-reduce per step (BASELINE north_star), eager launches so that the
+    # collective can be issued behind each step; N=1 / explicit buckets: steps replayed from hipGraphs
+    bucket = a.loss_bucket if a.loss_bucket is not None else (1 if world > 1 else None)
+    per_step_collective = world > 1 and bucket == 1
+    launch = "eager" if per_step_collective else a.launch
+    M = max(1, min(a.graph_steps, K)) if launch == "graph" else 1
+    if bucket is None or (launch == "graph" and world > 1):
+        bucket = M if launch == "graph" else (bucket or 1)
 
     # ---- the step sequence, eager or captured into hipGraphs (two, alternating, so that an
     # all-reduce of one loss ring can overlap the replay that fills the other)
-    rings = [torch.zeros(max(M, bucket), dtype=torch.float32, device=dev) for _ in range(2)]
+    rings = [torch.zeros(max(M, bucket, a.graph_steps), dtype=torch.float32, device=dev) for _ in range(2)]
     ws = wl.new_workspace()
     wl.step(rings[0].data_ptr(), ws, cur_stream(dev))       # first touch outside any capture
     torch.cuda.synchronize()
-    graphs = []
-    if a.launch == "graph":
+
+    def capture(m):
+        gs = []
         for r in rings:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 s = cur_stream(dev)
-                for j in range(M):
+                for j in range(m):
                     wl.step(r.data_ptr() + 4 * j, ws, s)
-            graphs.append(g)
+            gs.append(g)
+        return gs
 
+    graphs = capture(M) if launch == "graph" else []
     pending = [None, None]
     state = {"i": 0}
 
-    def run_steps(n):
+    def run_steps(n, launch=launch, graphs=graphs, M=M, bucket=bucket):
         """exactly n steps; N>1: loss contributions all-reduced every `bucket` steps"""
         done = 0
         while done < n:
@@ -204,11 +286,11 @@ def main():
             if pending[k] is not None:                      # ring k is about to be overwritten
                 pending[k].wait()
                 pending[k] = None
-            if a.launch == "graph" and n - done >= M:
+            if launch == "graph" and n - done >= M:
                 graphs[k].replay()
                 m = M
             else:
-                m = min(bucket, n - done) if a.launch == "eager" else n - done
+                m = min(bucket, n - done) if launch == "eager" else n - done
                 s = cur_stream(dev)
                 for j in range(m):
                     wl.step(rings[k].data_ptr() + 4 * j, ws, s)
@@ -227,16 +309,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, **kw):
+        """exactly n steps between two fences; max over ranks -> seconds"""
+        fence()
+        t0 = time.perf_counter()
+        run_steps(n, **kw)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
+
     run_steps(W)
-    fence()
-    t0 = time.perf_counter()
-    run_steps(K)
-    fence()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = float(tmax.item())
+    # K steps are timed in one bracketed region.  A short K (the driver uses 20) is one or two graph
+    # replays, i.e. mostly launch latency of the replay itself: the region is then repeated and the
+    # median taken (SURVEY 8d: >= 50 timed iterations), every repeat timing exactly K steps.
+    repeats = 1 if K >= 100 else min(15, max(3, -(-150 // max(K, 1))))
+    els = sorted(timed(K) for _ in range(repeats))
+    el = els[len(els) // 2]
+
+    # secondary figure for N>1: the same steps with the loss all-reduce amortised over a graph replay
+    bucketed = None
+    if per_step_collective and a.launch == "graph":
+        Mb = max(1, min(a.graph_steps, K))
+        gb = capture(Mb)
+        run_steps(Mb, launch="graph", graphs=gb, M=Mb, bucket=Mb)
+        nb = max(Mb, K // Mb * Mb)
+        elb = timed(nb, launch="graph", graphs=gb, M=Mb, bucket=Mb)
+        bucketed = {"value": round(B_total(world, wl, a) * nb / elb, 1), "unit": "samples/s", "steps": nb,
+                    "ms_per_step": round(elb / nb * 1e3, 6), "launch": "graph", "graph_steps": Mb,
+                    "loss_allreduce_bucket": Mb}
 
     # ---- dominant kernel: per-launch duration from HIP events on the launch stream
     n_ev = 200 if variant != "blank" else 20
@@ -259,35 +363,40 @@ def main():
 
     out = None
     if rank == 0:
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("%s_B%d" % (variant, B), {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = "profiles/traffic.json (rocprofv3 --pmc passes of tools/profile.sh, not this run)"
         # average launch duration: n_ev launches between two HIP events on the launch stream (this
         # includes the inter-launch gap and is what rocprofv3 --stats reports, profiles/*.md); the
         # per-launch bracketed figure carries ~2 us of event overhead and is kept for reference
         achieved = wl.alg_bytes / (b2b_us * 1e-6) / 1e9
-        sps = B * world * K / el
+        sps = Bg * K / el
         out = {
             "metric": "ctc_samples_per_sec", "value": round(sps, 1), "unit": "samples/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 6),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl.name, "variant": variant, "per_gpu_batch": B, "global_batch": B * world,
+            "config": {"workload": wl.name, "variant": variant, "per_gpu_batch": B, "global_batch": Bg,
                        "T": wl.T, "C": wl.C, "S": wl.S, "parallelism": "dp%d (batch-sharded)" % world,
                        "collective": (a.backend if world > 1 else None),
-                       "launch": a.launch, "graph_steps": M if a.launch == "graph" else None,
+                       "launch": launch, "graph_steps": M if launch == "graph" else None,
                        "loss_allreduce_bucket": bucket if world > 1 else None,
+                       "timed_repeats_median_of": repeats,
                        "step": "fused loss+grad launch + scale_grad launch (loss.backward(), grad_out=1)"},
-            "lattice_cells_per_sec": round(wl.cells * world * K / el, 1),
-            "lattice_cells_per_sec_2Sp1": round(B * wl.T * (2 * wl.S + 1) * world * K / el, 1),
+            "lattice_cells_per_sec": round(wl.cells * (Bg / B) * K / el, 1),
+            "lattice_cells_per_sec_2Sp1": round(Bg * wl.T * (2 * wl.S + 1) * K / el, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "%s fused loss+grad" % variant, "kernel_us_avg": round(b2b_us, 3),
                          "kernel_us_event_bracketed_avg": round(kern_us, 3),
                          "kernel_us_event_bracketed_median": round(per[len(per) // 2], 3),
                          "algorithmic_bytes_per_launch": wl.alg_bytes},
         }
+        if bucketed is not None:
+            out["bucketed"] = bucketed
         # parity of THIS batch against the float64 oracle (untimed)
         ref = oracle_step(wl, threads=min(16, os.cpu_count() or 1), dtype=np.float64)
         torch.cuda.synchronize()
@@ -295,17 +404,27 @@ def main():
         out["parity"] = {"checker": "oracle/ctc_oracle.c float64",
                          "max_rel_err_nll": float((np.abs(nll_dev - ref["nll"]) / np.maximum(1.0, np.abs(ref["nll"]))).max()),
                          "max_abs_err_nll": float(np.abs(nll_dev - ref["nll"]).max()),
-                         "max_abs_err_grad": float(np.abs(wl.grad.cpu().numpy() - ref["grad"] * (1.0 / world)).max())}
+                         "max_abs_err_grad": float(np.abs(wl.grad.cpu().numpy() - ref["grad"] * (B / Bg)).max())}
         del ref
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
+            if variant == "blank":
+                out["cpu_baseline_torch"] = torch_cpu_ctc_baseline(wl, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not a.no_eager_python:
+            out["eager_python"] = {"us_per_step": round(eager_python_step(wl, 300 if variant != "blank" else 20), 2),
+                                   "launch": "eager-python",
+                                   "what": "CTCLoss.apply(...) + loss.backward() issued eagerly (train.py:427,444), host-inclusive"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
+
+
+def B_total(world, wl, a):
+    return a.global_batch if a.scaling == "strong" else wl.B * world
 
 
 if __name__ == "__main__":

@@ -537,7 +537,8 @@ extern "C" int ctc_amd_scale_grad(float *grad, const float *grad_out, size_t n, 
     // small grid: in the common case (grad_out == 1) every block only reads one float and
     // leaves, so the launch itself is the cost (2048 blocks: 4.7 us, 256 blocks: ~2 us)
     size_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 256) blocks = 256;
+    static const size_t cap = getenv("CTC_AMD_SCALE_BLOCKS") ? (size_t)atoi(getenv("CTC_AMD_SCALE_BLOCKS")) : 256;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(scale_grad_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), grad, grad_out, n);
