@@ -24,23 +24,37 @@ import torch
 
 from . import _lib
 
-_workspaces = {}
+_workspaces = {}           # (device index, raw stream, variant) -> [tensor, ...]; the LAST one is current
+_ws_need = {}              # (variant, T, B, C, S) -> bytes
 _VALIDATE = os.environ.get("CTC_AMD_VALIDATE", "0") == "1"
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _stream_handle(device):
+    """hipStream_t of torch's current stream on `device` as an integer (no Stream object built)."""
+    if _raw_stream is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _workspace(variant, T, B, C, S, device):
-    """Zero-initialised once, one per (device, stream): see include/ctc_amd.h."""
-    need = _lib.load().ctc_amd_workspace_bytes(variant, T, B, C, S)
-    key = (device.index, _stream_handle(device), variant)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.zeros(need, dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
-    return ws
+def _workspace(variant, T, B, C, S, device, stream=None):
+    """Zero-initialised once, one per (device, stream): see include/ctc_amd.h.
+
+    A workspace that has become too small is SUPERSEDED, never freed: a hipGraph captured earlier
+    still holds its raw pointer (the calls are capture-safe, tests capture after an eager warm-up),
+    and replaying it must not write counters and lattices into memory the allocator has handed to
+    someone else.  The list only grows when a larger shape arrives (a handful of times per process)."""
+    shape = (variant, T, B, C, S)
+    need = _ws_need.get(shape)
+    if need is None:
+        need = _ws_need[shape] = _lib.load().ctc_amd_workspace_bytes(variant, T, B, C, S)
+    key = (device.index, _stream_handle(device) if stream is None else stream, variant)
+    held = _workspaces.get(key)
+    if held is None:
+        held = _workspaces[key] = []
+    if not held or held[-1].numel() < need:
+        held.append(torch.zeros(need, dtype=torch.uint8, device=device))
+    return held[-1]
 
 
 class _NullCtx:
@@ -68,6 +82,9 @@ def _require_hip(x, name):
 def _lengths(v, B, lo_name, device, hi, lo=1):
     """-> int64 device tensor [B]; values are validated on the host only when that
     costs no device synchronisation (CPU input) or CTC_AMD_VALIDATE=1."""
+    if (v.__class__ is torch.Tensor and v.is_cuda and v.dtype is torch.int64 and v.device == device and v.dim() == 1
+            and v.shape[0] == B and v.is_contiguous() and not _VALIDATE):
+        return v                                    # the usual case (train.py:397-399): nothing to convert or check
     if not isinstance(v, torch.Tensor):
         v = torch.as_tensor(v, dtype=torch.int64)
     if v.dim() != 1 or v.numel() != B:
@@ -79,7 +96,7 @@ def _lengths(v, B, lo_name, device, hi, lo=1):
         if h.numel() and (int(h.min()) < lo or int(h.max()) > hi):
             raise ValueError("ctc_amd: %s must lie in [%d, %d]" % (lo_name, lo, hi))
     if v.dtype == torch.int64 and v.device == device and v.is_contiguous():
-        return v                                    # the usual case (train.py:397-399): nothing to convert
+        return v
     return v.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
 
 
@@ -94,66 +111,73 @@ def _variant_of(targets):
 
 def _launch(variant, x, targets, in_len, tgt_len, want_grad, batch_total, blank=0):
     """Validate, allocate outputs and enqueue the fused kernel.  -> (loss, nll, grad|None)"""
-    _require_hip(x, "log_probs")
+    if x.__class__ is not torch.Tensor and not isinstance(x, torch.Tensor) or not x.is_cuda:
+        _require_hip(x, "log_probs")
     if x.dim() != 3:
         raise ValueError("ctc_amd: log_probs must be [T,B,C], got %s" % (tuple(x.shape),))
-    if x.dtype != torch.float32:
+    if x.dtype is not torch.float32:
         raise ValueError("ctc_amd: log_probs must be float32 (the engine computes in fp32), got %s" % x.dtype)
     T, B, C = x.shape
     if T < 1 or B < 1 or C < 1:
         raise ValueError("ctc_amd: empty log_probs %s" % (tuple(x.shape),))
     dev = x.device
-    xs = x.detach()
-    if xs.stride(2) != 1:
+    xs = x.detach() if x.requires_grad else x
+    st, sb, sc = xs.stride()
+    if sc != 1:
         xs = xs.contiguous()
+        st, sb, sc = xs.stride()
     if not isinstance(targets, torch.Tensor):
         raise ValueError("ctc_amd: targets must be a tensor")
-    if targets.shape[0] != B:
-        raise ValueError("ctc_amd: targets batch %d != log_probs batch %d" % (targets.shape[0], B))
-    S = targets.shape[1]
+    tshape = targets.shape
+    if tshape[0] != B:
+        raise ValueError("ctc_amd: targets batch %d != log_probs batch %d" % (tshape[0], B))
+    S = tshape[1]
     if S < 1:
         raise ValueError("ctc_amd: targets need at least one label column")
+    tdt = targets.dtype
     if variant == _lib.BINARY:
-        if targets.shape[2] != C:
-            raise ValueError("ctc_amd: binary targets last dim %d != C %d" % (targets.shape[2], C))
-        tg = targets if (targets.device == dev and targets.dtype == torch.float32 and targets.is_contiguous()) \
+        if tshape[2] != C:
+            raise ValueError("ctc_amd: binary targets last dim %d != C %d" % (tshape[2], C))
+        tg = targets if (tdt is torch.float32 and targets.device == dev and targets.is_contiguous()) \
             else targets.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
     else:
-        if targets.dtype not in (torch.int32, torch.int64):
+        if tdt is not torch.int32 and tdt is not torch.int64:
             targets = targets.long()
         tg = targets if (targets.device == dev and targets.is_contiguous()) else \
             targets.to(device=dev, non_blocking=True).contiguous()
     il = _lengths(in_len, B, "input_lengths", dev, T)
     tl = _lengths(tgt_len, B, "target_lengths", dev, S, lo=0 if variant == _lib.BLANK else 1)
-    total = B if batch_total is None else int(batch_total)
-    nll = torch.empty(B, dtype=torch.float32, device=dev)
-    loss = torch.empty((), dtype=torch.float32, device=dev)
+    scale = 1.0 / (B if batch_total is None else int(batch_total))
+    out = torch.empty(B + 1, dtype=torch.float32, device=dev)       # nll[B] and the loss behind it: one allocation
     grad = torch.empty((T, B, C), dtype=torch.float32, device=dev) if want_grad else None
     lib = _lib.load()
     with _on_device(dev):
-        ws = _workspace(variant, T, B, C, S, dev)
         stream = _stream_handle(dev)
+        ws = _workspace(variant, T, B, C, S, dev, stream)
         gp = grad.data_ptr() if want_grad else None
-        scale = 1.0 / total
+        op = out.data_ptr()
         if variant == _lib.NOBLANK:
             rc = lib.ctc_amd_noblank_loss_grad(
-                xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(), int(tg.dtype == torch.int64),
+                xs.data_ptr(), st, sb, tg.data_ptr(), int(tg.dtype is torch.int64),
                 il.data_ptr(), tl.data_ptr(), T, B, C, S, scale, scale,
-                nll.data_ptr(), loss.data_ptr(), gp, ws.data_ptr(), stream)
-            _lib.check(rc, "ctc_amd_noblank_loss_grad")
+                op, op + 4 * B, gp, ws.data_ptr(), stream)
+            if rc:
+                _lib.check(rc, "ctc_amd_noblank_loss_grad")
         elif variant == _lib.BINARY:
             rc = lib.ctc_amd_binary_loss_grad(
-                xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(),
+                xs.data_ptr(), st, sb, tg.data_ptr(),
                 il.data_ptr(), tl.data_ptr(), T, B, C, S, scale, scale,
-                nll.data_ptr(), loss.data_ptr(), gp, ws.data_ptr(), stream)
-            _lib.check(rc, "ctc_amd_binary_loss_grad")
+                op, op + 4 * B, gp, ws.data_ptr(), stream)
+            if rc:
+                _lib.check(rc, "ctc_amd_binary_loss_grad")
         else:
             rc = lib.ctc_amd_blank_loss_grad(
-                xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(), int(tg.dtype == torch.int64),
+                xs.data_ptr(), st, sb, tg.data_ptr(), int(tg.dtype is torch.int64),
                 il.data_ptr(), tl.data_ptr(), T, B, C, S, int(blank), scale, scale,
-                nll.data_ptr(), loss.data_ptr(), gp, ws.data_ptr(), stream)
-            _lib.check(rc, "ctc_amd_blank_loss_grad")
-    return loss, nll, grad
+                op, op + 4 * B, gp, ws.data_ptr(), stream)
+            if rc:
+                _lib.check(rc, "ctc_amd_blank_loss_grad")
+    return out[B], out[:B], grad
 
 
 def _scaled_grad(ctx, gout):
@@ -164,13 +188,14 @@ def _scaled_grad(ctx, gout):
         x, targets = ctx.saved_tensors
         variant, batch_total, blank = ctx.meta
         _, _, grad = _launch(variant, x, targets, ctx.lens[0], ctx.lens[1], True, batch_total, blank)
-    g = gout.detach()
-    if g.dtype != torch.float32 or g.device != grad.device or not g.is_contiguous():
-        g = g.to(device=grad.device, dtype=torch.float32).contiguous()
-    with _on_device(grad.device):
-        rc = _lib.load().ctc_amd_scale_grad(grad.data_ptr(), g.data_ptr(), grad.numel(),
-                                            _stream_handle(grad.device))
-    _lib.check(rc, "ctc_amd_scale_grad")
+    g = gout
+    if g.dtype is not torch.float32 or g.device != grad.device or not g.is_contiguous() or g.requires_grad:
+        g = g.detach().to(device=grad.device, dtype=torch.float32).contiguous()
+    dev = grad.device
+    with _on_device(dev):
+        rc = _lib.load().ctc_amd_scale_grad(grad.data_ptr(), g.data_ptr(), grad.numel(), _stream_handle(dev))
+    if rc:
+        _lib.check(rc, "ctc_amd_scale_grad")
     return grad
 
 

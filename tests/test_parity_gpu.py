@@ -254,7 +254,9 @@ def test_blank_vs_torch_cpu(dev, shape, var_T, schedule, monkeypatch):
     fb = np.array(feasible)
     assert (np.abs(r["nll"][fb] - ref["nll"][fb]) <= 1e-5 * np.maximum(1, np.abs(ref["nll"][fb]))).all()
     # (fp32 scans in the log domain: the error of a posterior grows with the length of the sequence)
-    assert np.abs(r["grad"][:, fb] - ref["grad"][:, fb]).max() < 2e-6 * max(1.0, 64.0 / B) * max(1.0, T / 300.0)
+    gerr = np.abs(r["grad"][:, fb] - ref["grad"][:, fb]).max()
+    print("blank %s %s var_T=%s: max grad err %.2e" % (shape, schedule, var_T, gerr))
+    assert gerr < min(1e-4, 2e-6 * max(1.0, 64.0 / B) * max(1.0, T / 300.0))   # never looser than north_star's 1e-4
     for b in range(B):
         if b not in feasible:
             assert np.isinf(r["nll"][b]) and np.isinf(ref["nll"][b])
@@ -557,3 +559,138 @@ def test_noblank_long_sequences_use_workspace_lattice(dev, shape):
     assert_close(r, ref, 2e-5 * max(1.0, 256.0 / B), nll_rtol=2e-5)     # T ~ 1e3: nll ~ 5e3, ulp 5e-4
     gamma, _ = ctc_amd.noblank_posteriors(x.to(dev), lab.to(dev), Tb.to(dev), L.to(dev))
     assert np.abs(np_(gamma).sum(axis=2)[0, :int(Tb[0])] - 1.0).max() < 1e-4
+
+
+# ------------------------------------------------------------------ BASELINE configs at full size
+@pytest.mark.parametrize("schedule", ["1", "0"])
+def test_blank_config5_full_size(dev, schedule, monkeypatch):
+    """BASELINE configs[4]: B=64 T=2000 C=1000 S=100, the persistent launch (1) and the three launches (0),
+    against the float64 oracle.  The bar is north_star's 1e-4 on the PER-SAMPLE gradient (the batch mean
+    carries 1/(B L_b)): the measured error is printed."""
+    import ctc_amd
+    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", schedule)
+    T, B, C, S = 2000, 64, 1000, 100
+    lp, tgt, Tb, L = synth_blank(0, T, B, C, S)
+    ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64, threads=16)
+    r = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
+    assert np.isfinite(ref["nll"]).all() and np.isfinite(r["nll"]).all()
+    nerr = (np.abs(r["nll"] - ref["nll"]) / np.maximum(1.0, np.abs(ref["nll"]))).max()
+    gerr = np.abs(r["grad"] - ref["grad"]).max()
+    per_sample = np.abs(r["grad"] - ref["grad"]).max(axis=(0, 2)) * B * np.maximum(np_(L), 1)
+    # what the reference's own arithmetic (torch fp32 on the CPU) makes of the same batch
+    lpc = lp.clone().requires_grad_(True)
+    torch.nn.functional.ctc_loss(lpc, tgt, Tb, L, blank=0, reduction="mean").backward()
+    terr = np.abs(np_(lpc.grad) - ref["grad"]).max()
+    print("config 5, schedule %s: max rel nll err %.2e; gradient of the batch-mean loss: max err %.2e "
+          "(torch fp32 CPU against the same float64 truth: %.2e); unnormalised per-sample occupancy: %.2e"
+          % (schedule, nerr, gerr, terr, per_sample.max()))
+    assert nerr <= 1e-5
+    # north_star: loss and input gradient within 1e-4 of the reference's output, which is the gradient of
+    # mean_b(nll_b / L_b).  (The fp32 log-domain scans lose precision with T -- alpha reaches -2e4 in log2
+    # units, one ulp there is 2e-3 -- exactly as the reference's fp32 kernel does; the unnormalised
+    # occupancies are good to ~1e-2 at T = 2000, printed above.)
+    assert gerr <= 1e-4 and gerr <= 4 * max(terr, 1e-6)
+    # size-independent properties: every live row of exp(lp) - occupancy sums to exp-sum - 1 = 0
+    assert np.abs(r["grad"].sum(axis=2)).max() < 1e-6
+
+
+@pytest.mark.parametrize("variant", ["noblank", "binary"])
+def test_config4_single_gpu_shape_full_size(dev, variant):
+    """B=2048 T=150 C=158 S<=20 (BASELINE configs[3] on one GPU: more samples than CUs) vs float64."""
+    import ctc_amd
+    T, B, C, S = 150, 2048, 158, 20
+    if variant == "noblank":
+        x, tg, Tb, L = synth_noblank(0, T, B, C, S)
+        ref = ctc_c.noblank_ctc(np_(x), np_(tg), np_(Tb), np_(L), np.float64, threads=16)
+        r = run_hip(ctc_amd.noblank_ctc_loss, x, tg, Tb, L, dev)
+        tol = 2e-6 * 256.0 / B
+    else:
+        x, tg, Tb, L = synth_binary(0, T, B, C, S)
+        ref = ctc_c.binary_ctc(np_(x), np_(tg), np_(Tb), np_(L), np.float64, threads=16)
+        r = run_hip(ctc_amd.binary_ctc_loss, x, tg, Tb, L, dev)
+        tol = 1e-7 * 256.0 / B
+    print("B=2048 %s: max grad err %.2e (tolerance %.2e)" % (variant, np.abs(r["grad"] - ref["grad"]).max(), tol))
+    assert_close(r, ref, tol)
+    assert np.abs(r["grad"].sum(axis=2)).max() < 1e-7 if variant == "noblank" else True
+
+
+def test_sharded_loss_hip_path_single_rank(dev):
+    """ShardedCTCLoss with the real (HIP) local compute, 1-rank degenerate mode: a shard of a
+    larger global batch reproduces its slice of the full-batch loss and gradient."""
+    import ctc_amd
+    from ctc_amd.distributed import ShardedCTCLoss, shard_bounds
+    T, B, C, S = 150, 64, 158, 20
+    x, lab, Tb, L = synth_noblank(3, T, B, C, S, var_T=True)
+    ref = ctc_c.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64, threads=8)
+    total, grads = 0.0, []
+    for rank in range(2):                                    # both shards, one after the other on this GPU
+        lo, hi = shard_bounds(B, rank, 2)
+        xs = x[:, lo:hi].contiguous().to(dev).requires_grad_(True)
+        res = ShardedCTCLoss(global_batch=B, variant="noblank")(xs, lab[lo:hi].to(dev), Tb[lo:hi].to(dev), L[lo:hi].to(dev))
+        res.backward()
+        total += float(res.value)                            # (no process group: value == local contribution)
+        grads.append(np_(xs.grad))
+    assert abs(total - float(ref["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+    assert np.abs(np.concatenate(grads, axis=1) - ref["grad"]).max() < 2e-6 * 256.0 / B
+    # variant taken from the targets, binary through the same wrapper
+    xb, y, Tbb, Lb = synth_binary(4, 40, 6, 30, 5)
+    refb = ctc_c.binary_ctc(np_(xb), np_(y), np_(Tbb), np_(Lb), np.float64)
+    xd = xb.to(dev).requires_grad_(True)
+    res = ShardedCTCLoss(global_batch=6)(xd, y.to(dev), Tbb.to(dev), Lb.to(dev))
+    res.backward()
+    assert abs(float(res.value) - float(refb["loss"])) < 1e-5 and np.abs(np_(xd.grad) - refb["grad"]).max() < 1e-6
+
+
+def test_superseded_workspace_stays_valid_for_captured_graphs(dev):
+    """A hipGraph captured at one shape keeps replaying correctly after an eager call with a LARGER shape
+    has made the hidden workspace grow (the old one must not be freed under the graph)."""
+    import ctc_amd
+    T, B, C, S = 300, 4, 40, 30                              # blank-CTC: the lattice lives in the workspace
+    lp, tgt, Tb, L = synth_blank(11, T, B, C, S)
+    ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xs = lp.to(dev).requires_grad_(True)
+        tg, il, tl = tgt.to(dev), Tb.to(dev), L.to(dev)
+        for _ in range(2):                                   # warm-up on the capture stream
+            xs.grad = None
+            loss, _ = ctc_amd.blank_ctc_loss(xs, tg, il, tl)
+            loss.backward()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        xs.grad = None
+        with torch.cuda.graph(g, stream=side):
+            loss, _ = ctc_amd.blank_ctc_loss(xs, tg, il, tl)
+            loss.backward()
+        # same stream, bigger shape: the cached workspace is superseded by a larger one
+        big = synth_blank(12, 2 * T, 2 * B, C, S)
+        xb = big[0].to(dev).requires_grad_(True)
+        lb, _ = ctc_amd.blank_ctc_loss(xb, big[1].to(dev), big[2].to(dev), big[3].to(dev))
+        lb.backward()
+        junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(16)]   # reuse whatever was freed
+        xs.grad.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        del junk
+    assert abs(float(loss) - float(ref["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+    assert np.abs(np_(xs.grad) - ref["grad"]).max() < 2e-6 * 64.0 / B
+
+
+def test_blank_persistent_launch_beside_a_busy_stream(dev, monkeypatch):
+    """The persistent blank-CTC launch (workgroups waiting for each other) while ANOTHER stream keeps the GPU
+    busy with a long kernel: it may be delayed, it must not hang or return poisoned values."""
+    import ctc_amd
+    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", "1")
+    T, B, C, S = 512, 40, 400, 60
+    lp, tgt, Tb, L = synth_blank(5, T, B, C, S)
+    ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64, threads=8)
+    a = torch.randn(4096, 4096, device=dev)
+    other = torch.cuda.Stream()
+    with torch.cuda.stream(other):
+        for _ in range(30):
+            a = torch.tanh(a @ a) * 0.01                     # a few ms of matrix work on the other stream
+    r = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
+    torch.cuda.synchronize()
+    assert np.isfinite(r["nll"]).all() and np.isfinite(r["grad"]).all()
+    assert (np.abs(r["nll"] - ref["nll"]) <= 1e-5 * np.maximum(1, np.abs(ref["nll"]))).all()
+    assert np.abs(r["grad"] - ref["grad"]).max() < 2e-6 * 64.0 / B * max(1.0, T / 300.0)
