@@ -34,17 +34,21 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return SO
+def build(force=False, verbose=False, extra_flags=(), name=None):
+    """name=None: the product library.  name="diag" (python -m ctc_amd.build --diag): the same sources with
+    -DCTC_AMD_DIAGNOSTICS -> lib/libctc_amd_diag.so, the library tools/ load (phase stamps, forced kernel
+    choices, the chain probe); any other name/flags: a variant for A/B runs or fault injection."""
+    so = SO if name is None else os.path.join(LIBDIR, "libctc_amd_%s.so" % name)
+    if name is None and not force and not _stale():
+        return so
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" if name is None else "obj_" + name)
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -56,10 +60,17 @@ def build(force=False, verbose=False):
         if verbose and out:
             print(out.decode())
         objs.append(obj)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO + ".tmp", *objs])
-    os.replace(SO + ".tmp", SO)
-    return SO
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so + ".tmp", *objs])
+    os.replace(so + ".tmp", so)
+    return so
+
+
+def build_diag(verbose=False):
+    return build(force=True, verbose=verbose, extra_flags=("-DCTC_AMD_DIAGNOSTICS",), name="diag")
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--diag" in sys.argv:
+        print(build_diag(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

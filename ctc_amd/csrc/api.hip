@@ -34,3 +34,14 @@ extern "C" size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int 
     if (variant == CTC_AMD_NOBLANK) bytes += ctc::noblank_extra_workspace(T, B, C, S);   // 0 while T x S fits in LDS
     return bytes;
 }
+
+extern "C" int ctc_amd_workspace_status(void *workspace, int clear, void *stream, unsigned *status_host)
+{
+    if (!workspace || !status_host) return CTC_AMD_ERR_BAD_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned *word = static_cast<unsigned *>(workspace) + 2;
+    hipError_t e = hipMemcpyAsync(status_host, word, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && clear && *status_host != 0) e = hipMemsetAsync(word, 0, sizeof(unsigned), s);
+    return (int)e;
+}

@@ -325,16 +325,24 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
     }
     stamp(p, 5);
     typedef const volatile __attribute__((address_space(3))) int lds_cvint;
+    bool starved = false;                                    // a bounded wait ran out: NaN outputs, status raised
     if (K != 1) __syncthreads();
     if (w == kBinWaves - 1 || !p.grad) {
         // nll / batch mean by the last wave (it owns the fewest rows): wait for the alpha scan
         if (K == 1 && Tb > 0) {
             int spins = 0;
-            while (*(lds_cvint *)sm.prog < Tb && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
+            while (*(lds_cvint *)sm.prog < Tb) {
+                if (++spins >= (1 << 20)) { starved = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
             lds_order();
         }
         if (w == kBinWaves - 1) {
-            const float nll = ok ? -sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;
+            float nll = ok ? -sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;
+            if (starved) {                                   // a bounded wait ran out: NaN, not a plausible number
+                nll = __builtin_nanf("");
+                raise_status(p.counter, kStatusBinaryStarved);
+            }
             publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
                                [](float x, int) { return x; });
         }
@@ -367,10 +375,12 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
 #pragma unroll
                 for (int i = 0; i < 4; ++i) t_hi = tt[i] >= 0 ? tt[i] : t_hi;
                 int spins = 0;
-                while ((*(lds_cvint *)sm.prog < t_hi + 1 || *(lds_cvint *)(sm.prog + 1) < Tlive - t_first) &&
-                       ++spins < (1 << 20))
+                while (*(lds_cvint *)sm.prog < t_hi + 1 || *(lds_cvint *)(sm.prog + 1) < Tlive - t_first) {
+                    if (++spins >= (1 << 20)) { starved = true; break; }
                     __builtin_amdgcn_s_sleep(8);
+                }
                 lds_order();
+                if (starved) raise_status(p.counter, kStatusBinaryStarved);
                 posterior_rows4(sm.al, sm.be, sm.em, tt, L, p.SP, 1.0f);
                 const int ti = tt[lane & 3];
                 const float *arow = sm.be + (ti >= 0 ? ti : 0) * p.SP;
@@ -402,7 +412,8 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
                     if (c < p.C) {
                         const float pr = v[r0 + i][j];       // sigmoid(x), kept from P1a
                         const float pq = pr * (1.0f - pr);
-                        stream_store(&g[c], live ? gs * (pr - acc[j][i]) * (pq * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f))) : 0.f);
+                        const float gv = live ? gs * (pr - acc[j][i]) * (pq * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f))) : 0.f;
+                        stream_store(&g[c], starved ? __builtin_nanf("") : gv);
                     }
                 }
             }
@@ -505,11 +516,12 @@ extern "C" int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_
     p.loss_scale = loss_scale; p.grad_scale = grad_scale;
     p.nll = nll; p.loss = loss; p.grad = grad;
     p.counter = static_cast<unsigned *>(workspace);
-    static const int debug_stop = getenv("CTC_AMD_DEBUG_STOP") ? atoi(getenv("CTC_AMD_DEBUG_STOP")) : 0;
+    static const int debug_stop = diag_env("CTC_AMD_DEBUG_STOP");
+    static const bool binary_valu = diag_env("CTC_AMD_BINARY_VALU") != 0;
     p.stop = debug_stop < 0 ? debug_stop : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // fast path: MFMA contractions, rows resident (T <= 160, C <= 256, images fit in LDS)
-    if (T <= kBinRows * kBinWaves && C <= 256 && !getenv("CTC_AMD_BINARY_VALU")) {
+    if (T <= kBinRows * kBinWaves && C <= 256 && !binary_valu) {
         BinaryParams q = p;
         q.SP = (p.SP + 3) / 4 * 4;                           // K padding of the gamma . Y product
         if (q.SP % K) q.SP = (q.SP + 4 * K - 1) / (4 * K) * (4 * K);

@@ -41,6 +41,9 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include <atomic>
+#include <cstdlib>
+
 #include "launch.hpp"
 
 namespace ctc {
@@ -120,7 +123,7 @@ __device__ __forceinline__ bool lds_wait_ge(const BlankParams &p, const int *fla
         if ((it & 4095) == 4095 && agent_load(p.sync) != 0) break;   // somebody already gave up
         __builtin_amdgcn_s_sleep(1);
     }
-    if (!ok) agent_store(p.sync, 1);
+    if (!ok) { agent_store(p.sync, 1); raise_status(p.counter, kStatusBlankStarved); }
     asm volatile("" ::: "memory");
     return ok;
 }
@@ -706,7 +709,7 @@ __device__ __forceinline__ bool wait_chains(const BlankParams &p, int b, int nee
         const int naps = max(min(max(need_f - vf, need_b - vb), 64), 24);   // ~ a nap (1 us) per 8 missing steps, 3 to 8
         for (int q = 0; q < naps; q += 8) __builtin_amdgcn_s_sleep(40);
     }
-    if (!ok) agent_store(p.sync, 1);
+    if (!ok) { agent_store(p.sync, 1); raise_status(p.counter, kStatusBlankStarved); }
     asm volatile("" ::: "memory");                           // nothing below moves above the poll
     return ok;
 }
@@ -972,31 +975,41 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void blank_fused_kernel(BlankP
     if (wid == nw / 2) bstamp(p, 14);
 }
 
-static int device_cus()
-{
-    static int cus[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
-    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 0;
-    return cus[dev];
-}
-
 // workgroups of blank_fused_kernel that are resident at once on this device (at most one per CU), 0 when unknown
 template <int K, bool VEC4>
 static int fused_capacity(size_t lds)
 {
-    static size_t cached_lds = ~(size_t)0;
-    static int cached = 0;
-    if (cached_lds != lds) {
-        int per_cu = 0;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(blank_fused_kernel<K, VEC4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blank_fused_kernel<K, VEC4>, kFusedWaves * kWave, lds) != hipSuccess)
-            per_cu = 0;
-        cached = per_cu >= 1 ? device_cus() : 0;
-        cached_lds = lds;
+    // per device (and per instantiation): the last LDS size asked about and its answer, packed into one
+    // atomic word so that concurrent host threads see a consistent pair
+    static std::atomic<unsigned long long> cache[kMaxDevices];
+    const int dev = current_device();
+    const unsigned long long key = (unsigned long long)lds << 16;
+    if (dev >= 0) {
+        const unsigned long long c = cache[dev].load(std::memory_order_acquire);
+        if (c != 0 && (c & ~0xffffull) == key) return (int)(c & 0xffff) - 1;
     }
-    return cached;
+    int per_cu = 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(blank_fused_kernel<K, VEC4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blank_fused_kernel<K, VEC4>, kFusedWaves * kWave, lds) != hipSuccess)
+        per_cu = 0;
+    const int cap = per_cu >= 1 ? device_cus() : 0;
+    if (dev >= 0) cache[dev].store(key | (unsigned long long)(cap + 1), std::memory_order_release);
+    return cap;
+}
+
+// schedule of the long-sequence path: -1 the library's own choice, 1 / 0 force / forbid the persistent launch
+// (ctc_amd_blank_set_schedule; the initial value comes from CTC_AMD_BLANK_FUSED, read once)
+static std::atomic<int> g_blank_schedule{-2};
+static int blank_schedule()
+{
+    int v = g_blank_schedule.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char *e = getenv("CTC_AMD_BLANK_FUSED");
+        v = e && e[0] == '1' ? 1 : (e && e[0] == '0' ? 0 : -1);
+        g_blank_schedule.store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 template <int K>
@@ -1015,7 +1028,7 @@ static int run_blank(BlankParams &p, hipStream_t s)
     p.Bp = (p.B + 63) & ~63;
     p.sync = reinterpret_cast<int *>(p.meta + p.Bp);
     p.nsync = blank_sync_ints(p.T, p.B);
-    static const int debug = getenv("CTC_AMD_BLANK_DEBUG") ? atoi(getenv("CTC_AMD_BLANK_DEBUG")) : 0;
+    static const int debug = diag_env("CTC_AMD_BLANK_DEBUG");
     p.debug = debug;
     const size_t row_lds = (((p.C + 3) & ~3) + 2 * p.NSP) * sizeof(float);   // a grad wave's occ[] + gam[] + nxt[]
     const bool vec4 = (p.C % 4 == 0) && p.C <= 4 * kWave * kMaxV4 && (p.st % 4 == 0) && (p.sb % 4 == 0) &&
@@ -1028,9 +1041,9 @@ static int run_blank(BlankParams &p, hipStream_t s)
     // 96x1000x100 425/411 (the chains take too many CUs from the workers), 64x1000x30 196/199, 64x400x30
     // 145/148, 32x400x30 132/119 (two states per lane: the plain chain kernel is fast), 32x2000x50 373/294
     // (rows too wide for the float4 loaders); over T at 64x1000x100: 50/53 at 128, 75/84 at 256, 122/150 at
-    // 512.  CTC_AMD_BLANK_FUSED=1 / 0 forces / forbids it (tests, measurements).
-    const char *force = getenv("CTC_AMD_BLANK_FUSED");
-    const bool forced = force && force[0] == '1', forbidden = force && force[0] == '0';
+    // 512.  ctc_amd_blank_set_schedule(1 / 0) forces / forbids it (tests, measurements).
+    const int schedule = blank_schedule();
+    const bool forced = schedule == 1, forbidden = schedule == 0;
     if (p.grad && !forbidden && p.T >= kFusedMinT && (int64_t)p.T * p.NSP * 4 < kPastLattice &&
         (int64_t)2 * p.T * p.B + 4096 < ((int64_t)1 << 31)) {
         // more than half of a CU's LDS per workgroup: one workgroup per CU, the chains share their SIMDs with nobody
@@ -1093,4 +1106,11 @@ extern "C" int ctc_amd_blank_loss_grad(const float *log_probs, int64_t stride_t,
     if (ns <= kWave * 2) return run_blank<2>(p, s);
     if (ns <= kWave * 4) return run_blank<4>(p, s);
     return run_blank<8>(p, s);
+}
+
+extern "C" int ctc_amd_blank_set_schedule(int mode)
+{
+    if (mode < -1 || mode > 1) return CTC_AMD_ERR_BAD_ARGUMENT;
+    g_blank_schedule.store(mode, std::memory_order_relaxed);
+    return 0;
 }

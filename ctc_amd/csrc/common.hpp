@@ -43,6 +43,23 @@ __device__ __forceinline__ void through_store(wt_f4 *p, wt_f4 v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// Workspace word 2 (bytes [8,12)): STATUS.  A bounded in-kernel wait that ran out ORs its bit in here
+// (and poisons the outputs it could not produce with NaN); nothing in the kernels ever clears it --
+// ctc_amd_workspace_status() reads / clears it from the host.  Never observed outside fault-injection
+// builds: the hand-offs cannot break unless a workgroup is starved for ~1 s.
+constexpr unsigned kStatusNoblankStarved = 1u, kStatusBinaryStarved = 2u, kStatusBlankStarved = 4u;
+__device__ __forceinline__ void raise_status(unsigned *counter, unsigned bit)
+{
+    if (lane_id() == 0) __hip_atomic_fetch_or(counter + 2, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Diagnostics (phase stamps, early exits) compile to nothing in the product library.
+#ifdef CTC_AMD_DIAGNOSTICS
+#define CTC_DIAG(p) ((p).stop)
+#else
+#define CTC_DIAG(p) 0
+#endif
+
 // Publish / consume points of LDS hand-offs between waves of a workgroup.  The hardware
 // completes a wave's LDS operations in order, so no wait is needed -- but the COMPILER must not
 // move a row access across the counter access (float rows and int counters do not alias for
@@ -239,8 +256,8 @@ struct ScalarLengths {
 template <typename P>
 __device__ __forceinline__ void stamp(const P &p, int slot)
 {
-    if (p.stop >= 0 || p.stop <= -100) return;
-    if (blockIdx.x == 0 && wave_id() == -p.stop - 1 && lane_id() == 0) {
+    if (CTC_DIAG(p) >= 0 || CTC_DIAG(p) <= -100) return;
+    if (blockIdx.x == 0 && wave_id() == -CTC_DIAG(p) - 1 && lane_id() == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
         o[0] = __builtin_amdgcn_s_memtime();
         o[1] = __builtin_amdgcn_s_memrealtime();
@@ -252,8 +269,8 @@ __device__ __forceinline__ void stamp(const P &p, int slot)
 template <typename P>
 __device__ __forceinline__ void stamp_setup(const P &p, int slot)
 {
-    if (p.stop > -100) return;
-    if (blockIdx.x == 0 && wave_id() == -p.stop - 100 && lane_id() == 0) {
+    if (CTC_DIAG(p) > -100) return;
+    if (blockIdx.x == 0 && wave_id() == -CTC_DIAG(p) - 100 && lane_id() == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
         o[0] = __builtin_amdgcn_s_memtime();
         o[1] = __builtin_amdgcn_s_memrealtime();

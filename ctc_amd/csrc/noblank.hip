@@ -20,8 +20,6 @@
 // (common.hpp), overlapped with P3.  HBM traffic = read x once, write grad once.
 // Shapes beyond the register-resident tiling (T > 160 rows per pass, C > 256) fall
 // back to re-reading rows from L2 in P3 / to strided row passes.
-#include <cstdlib>
-
 #include "lattice.hpp"
 #include "launch.hpp"
 
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
         sm.em[i - kPrefetch * p.SP] = kNeg;
         sm.em[p.T * p.SP + i] = kNeg;
     }
-    if (p.stop == 1) return;
+    if (CTC_DIAG(p) == 1) return;
     stamp(p, 1);
 
     // P1 (passes beyond the first are processed first so that pass 0 stays resident)
@@ -301,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
     }
     stamp(p, 2);
     __syncthreads();
-    if (p.stop == 2) return;
+    if (CTC_DIAG(p) == 2) return;
     stamp(p, 3);
 
     // P2
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
     }
     stamp(p, 4);
     __syncthreads();
-    if (p.stop == 3) return;
+    if (CTC_DIAG(p) == 3) return;
     stamp(p, 5);
 
     const float nll = ok ? -sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;   // readout, :58-68,139
@@ -357,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
                 if (t0 + r < Tlive)
                     posterior_row<true>(sm.al, sm.be, sm.em, sm.nxt, sm.dup, t0 + r + sub,
                                   r + sub < kRows && t0 + r + sub < Tlive, L, p.SP, G);
-            if (p.stop == 4) continue;
+            if (CTC_DIAG(p) == 4) continue;
             stamp(p, 6);
             if (base == 0) {
                 rows.grad(p, sm, b, t0, Tlive, first);
@@ -438,11 +436,11 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     p.in_len = in_len; p.tgt_len = tgt_len;
     p.T = T; p.B = B; p.C = C; p.S = S;
     p.SP = (S + K - 1) / K * K;
-    static const int debug_stop = getenv("CTC_AMD_DEBUG_STOP") ? atoi(getenv("CTC_AMD_DEBUG_STOP")) : 0;
+    static const int debug_stop = diag_env("CTC_AMD_DEBUG_STOP");
     p.stop = debug_stop;
     p.loss_scale = loss_scale; p.grad_scale = grad_scale;
     p.nll = nll; p.loss = loss; p.grad = grad; p.gamma = nullptr;
-    static const bool debug_nograd = getenv("CTC_AMD_DEBUG_NOGRAD") != nullptr;   // diagnostic: forward only
+    static const bool debug_nograd = diag_env("CTC_AMD_DEBUG_NOGRAD") != 0;       // diagnostic: forward only
     if (debug_nograd) p.grad = nullptr;
     p.counter = static_cast<unsigned *>(workspace);
     p.lattice = nullptr; p.slab = 0;
@@ -456,22 +454,17 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int ch = C <= 256 ? (C + kWave - 1) / kWave : 0;
     // common case (S <= 64, C <= 256, T <= 168): the pipelined schedule
-    static const bool no_pipe = getenv("CTC_AMD_NOPIPE") != nullptr;
+    static const bool no_pipe = diag_env("CTC_AMD_NOPIPE") != 0;
     if (K == 1 && ch >= 1 && T <= kPipeMaxT && !no_pipe && !p.lattice) {
         const dim3 grid(B), block(kThreads);
-        static const int cus = [] {
-            int dev = 0, n = 256;
-            if (hipGetDevice(&dev) == hipSuccess)
-                (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            return n;
-        }();
+        const int cus = device_cus();                           // (per device: a process may drive several)
         // extended-range linear lattice (noblank_xr.hpp) wherever its 8-byte cells fit
-        static const bool no_xr = getenv("CTC_AMD_NOXR") != nullptr;
+        static const bool no_xr = diag_env("CTC_AMD_NOXR") != 0;
         const size_t xsmem = xr_smem_bytes(T, p.SP, C);
         const bool dual = B > cus && 2 * smem <= kMaxLds;    // more samples than CUs: two workgroups per CU
         // lean four-rows-per-wave workers (noblank_r16.hpp): 8-byte aligned rows, S <= 31
-        static const bool no_r16 = getenv("CTC_AMD_NOR16") != nullptr;
-        static const bool force_r16 = getenv("CTC_AMD_R16_ALWAYS") != nullptr;
+        static const bool no_r16 = diag_env("CTC_AMD_NOR16") != 0;
+        static const bool force_r16 = diag_env("CTC_AMD_R16_ALWAYS") != 0;
         const bool aligned = C % 2 == 0 && stride_t % 2 == 0 && stride_b % 2 == 0 &&
                              reinterpret_cast<uintptr_t>(x) % 8 == 0 && reinterpret_cast<uintptr_t>(grad) % 8 == 0;
         const size_t rsmem = r16_smem_bytes(T, p.SP, C);
@@ -535,10 +528,10 @@ extern "C" int ctc_amd_scale_grad(float *grad, const float *grad_out, size_t n, 
     if (!grad || !grad_out) return CTC_AMD_ERR_BAD_ARGUMENT;
     if (n == 0) return 0;
     // small grid: in the common case (grad_out == 1) every block only reads one float and
-    // leaves, so the launch itself is the cost (2048 blocks: 4.7 us, 256 blocks: ~2 us)
+    // leaves, so the launch itself is the cost; 64 blocks still scale 24 MB in ~15 us when they must
     size_t blocks = (n / 4 + 255) / 256;
-    static const size_t cap = getenv("CTC_AMD_SCALE_BLOCKS") ? (size_t)atoi(getenv("CTC_AMD_SCALE_BLOCKS")) : 256;
-    if (blocks > cap) blocks = cap;
+    // (the launch costs one kernel boundary, ~1.7 us in a graph, whatever the grid: 1 to 256 blocks measured the same)
+    if (blocks > 64) blocks = 64;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(scale_grad_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), grad, grad_out, n);
@@ -586,6 +579,7 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
     }
 }
 
+#ifdef CTC_AMD_DIAGNOSTICS
 // Diagnostic entry point (tools/chain_probe.py), not part of include/ctc_amd.h: the lattice chains of
 // noblank_r16.hpp alone, every emission row pre-published; out[0], out[1] = shader cycles of the
 // alpha / beta chain.
@@ -600,3 +594,4 @@ extern "C" int ctc_amd_debug_chain_probe(int T, int SP, int waves_alive, int gri
     return launch<r16_chain_probe_kernel>(dim3(grid), dim3(kThreads), smem, static_cast<hipStream_t>(stream), p,
                                           static_cast<unsigned long long *>(out), waves_alive);
 }
+#endif

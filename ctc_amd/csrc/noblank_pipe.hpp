@@ -81,6 +81,7 @@ __device__ __forceinline__ float lattice_chain_sync(const NoblankParams &p, cons
     typedef const volatile __attribute__((address_space(3))) int lds_cvint;
     const int *cp = cnt + (lane < kPipeWorkers ? lane : 0);
     int seen = *(lds_cvint *)cp;
+    bool starved = false;                                    // a bounded wait ran out: NaN instead of a plausible number
     auto wait_upto = [&](int i_last) {                       // rows of steps 0..i_last must be published
         const int q = pos0 + (i_last < Tb ? i_last : Tb - 1);
         int need = 0;
@@ -88,7 +89,8 @@ __device__ __forceinline__ float lattice_chain_sync(const NoblankParams &p, cons
         else if (q >= lane) need = 2 * ((q - lane) / kPipeWorkers) + (FWD ? 1 : 2);
         if (lane >= kPipeWorkers) need = 0;
         int spins = 0;
-        while (__builtin_amdgcn_ballot_w64(seen < need) != 0 && ++spins < kSpinLimit) {
+        while (__builtin_amdgcn_ballot_w64(seen < need) != 0) {
+            if (++spins >= kSpinLimit) { starved = true; break; }
             __builtin_amdgcn_s_sleep(1);
             seen = *(lds_cvint *)cp;
         }
@@ -146,6 +148,10 @@ __device__ __forceinline__ float lattice_chain_sync(const NoblankParams &p, cons
     lds_order();
     *prog = Tb;
     __builtin_amdgcn_s_setprio(0);
+    if (starved) {
+        raise_status(p.counter, kStatusNoblankStarved);
+        return __builtin_nanf("");
+    }
     return a;
 }
 
@@ -303,9 +309,13 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
         lds_order();
         if (lane == 0) sm.dummy[7] = 1.0f;                   // tables ready (same wave: LDS stores in order)
     }
+    bool starved = false;                                    // a bounded wait ran out: NaN gradient rows, status raised
     {
         int spins = 0;
-        while (lds_now(sm.dummy + 7) == 0.f && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(4);
+        while (lds_now(sm.dummy + 7) == 0.f) {
+            if (++spins >= kSpinLimit) { starved = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
         lds_order();
     }
     int first[CH];
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
     const int Tlive = Tb;                                    // ok <=> an alignment exists (L_b <= T_b)
     const int lcl = lane < p.SP ? lane : 0;
     const bool in = lane < L;
-    const float gsc = p.grad_scale;
+    const float gsc0 = p.grad_scale;
     float shift = 0.f;                                       // row shift of the posterior softmax
     bool have_shift = false;
     const bool pair = p.SP <= 32;                            // two posterior rows per wave pass
@@ -346,12 +356,15 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
         }
         if (need_a > 0) {
             int spins = 0;
-            while ((*(lds_cvint *)(sm.cnt + kPipeWorkers) < need_a || *(lds_cvint *)(sm.cnt + kPipeWorkers + 1) < need_b) &&
-                   ++spins < kSpinLimit)
+            while (*(lds_cvint *)(sm.cnt + kPipeWorkers) < need_a || *(lds_cvint *)(sm.cnt + kPipeWorkers + 1) < need_b) {
+                if (++spins >= kSpinLimit) { starved = true; break; }
                 __builtin_amdgcn_s_sleep(8);
+            }
             lds_order();                                     // lattice rows are read only after the look
         }
-        if (p.stop < 0) stamp(p, 3 + (2 - gq));             // diagnostic: groups 2,1,0 -> slots 3,4,5
+        if (starved) raise_status(p.counter, kStatusNoblankStarved);
+        const float gsc = starved ? __builtin_nanf("") : gsc0;
+        if (CTC_DIAG(p) < 0) stamp(p, 3 + (2 - gq));             // diagnostic: groups 2,1,0 -> slots 3,4,5
         // gamma_t = softmax_l(alpha_t + beta'_t - e_t): row-normalised posterior (lattice.hpp).
         // Any shift gives the same softmax; every row's log-normaliser equals -nll up to the
         // rounding of the two scans, so the maximum found for the first (middle) group serves all

@@ -236,6 +236,9 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     __builtin_amdgcn_s_setprio(3);                           // the chains are the critical path
 #endif
     wait_upto(kPrefetch + 1);
+#ifdef CTC_AMD_FAULT_INJECT                                  // tests/test_status.py: sample 0's alpha chain "starves"
+    if (FWD && blockIdx.x == 0) starved = true;
+#endif
     int i = 1;
     {                                                        // step 0: u = p on the start state only
         const int start = FWD ? 0 : L - 1, x = FWD ? 0 : Tb - 1;
@@ -264,12 +267,12 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
         ring[0] = r0[FWD ? 0 : 1];                           // steps i, i+1
         ring[1] = r0[FWD ? 1 : 0];                           // steps i+2, i+3
     }
-    const unsigned long long loop_t0 = p.stop == -77 ? __builtin_amdgcn_s_memtime() : 0;   // (chain probe only)
+    const unsigned long long loop_t0 = CTC_DIAG(p) == -77 ? __builtin_amdgcn_s_memtime() : 0;   // (chain probe only)
     for (; i + kR16Block <= Tb; i += kR16Block) {
         lds_order();
         *prog = i;                                           // steps < i are done (every lane, same value)
         if (have < G) wait_upto(i + kR16Block - 1 + kPrefetch);
-        if (p.stop < 0) stamp(p, 2 + i / 16);       // diagnostic: block starts -> slots 2..10
+        if (CTC_DIAG(p) < 0) stamp(p, 2 + i / 16);       // diagnostic: block starts -> slots 2..10
         renorm();
 #pragma unroll
         for (int q = 0; q < kPairs; ++q) {
@@ -287,7 +290,7 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
         rb += D * kPairs;
         wb += D * kPairs;
     }
-    if (p.stop == -77 && lane == 0)
+    if (CTC_DIAG(p) == -77 && lane == 0)
         reinterpret_cast<unsigned long long *>(p.counter)[FWD ? 0 : 1] = __builtin_amdgcn_s_memtime() - loop_t0;
     lds_order();
     *prog = i;
@@ -314,7 +317,10 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     // alpha[T_b-1, L_b-1] from where the chain stored it (the registers may hold overrun steps);
     // a hand-off that ran out of patience poisons the sample instead of returning a plausible number
     cell_t fin = (FWD ? sm.al : sm.be)[(size_t)(L - 1) * sm.TP + (FWD ? Tb - 1 : 0)];
-    if (starved) fin = make_cell(__builtin_nanf(""), 0);
+    if (starved) {
+        raise_status(p.counter, kStatusNoblankStarved);
+        fin = make_cell(__builtin_nanf(""), 0);
+    }
     return fin;
 }
 
@@ -456,11 +462,11 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     const int rho = lane >> 4, i16 = lane & 15;              // row of the group, position inside the row
     const float ninf = -__builtin_inff();
 
-    if (p.stop == 1) return;                                 // diagnostic: cost of the bare dispatch
+    if (CTC_DIAG(p) == 1) return;                                 // diagnostic: cost of the bare dispatch
     stamp(p, 0);
     stamp_setup(p, 0);
     auto spread = [&](int which) {                           // diagnostic (stop == -50): entry / exit times of
-        if (p.stop != -50 || w != 1 || lane != 0) return;    // the first, middle and last workgroup, wave 1
+        if (CTC_DIAG(p) != -50 || w != 1 || lane != 0) return;    // the first, middle and last workgroup, wave 1
         const int bid = blockIdx.x, nb = gridDim.x;
         const int slot = bid == 0 ? 0 : bid == nb / 2 ? 2 : bid == nb - 1 ? 4 : -1;
         if (slot < 0) return;
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     stamp(p, 1);
     stamp_setup(p, 5);
-    if (p.stop == 2) return;                                 // diagnostic: dispatch + setup (+ loads in flight)
+    if (CTC_DIAG(p) == 2) return;                                 // diagnostic: dispatch + setup (+ loads in flight)
 
     if (Tb == 0) {                                           // no alignment exists: nll = 1e13, zero gradient
         if (w == 0)
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(cell_k(a) - kXrBias)) * kLn2 : -kNeg;
             if (am != am) nll = am;                          // starved hand-off: NaN, not a plausible number
             publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
-            if (p.stop == -50 && lane == 0) {                // diagnostic: when the alpha wave (loss ticket) is done
+            if (CTC_DIAG(p) == -50 && lane == 0) {                // diagnostic: when the alpha wave (loss ticket) is done
                 const int bid = blockIdx.x, nb = gridDim.x;
                 const int slot = bid == 0 ? 6 : bid == nb / 2 ? 7 : bid == nb - 1 ? 8 : -1;
                 if (slot >= 0) {
@@ -600,7 +606,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         const bool live = t >= 0 && t < Tb;
         float m = x.max(maskv);
         row16_allmax(m);
-        if (p.stop < 0 && g == 0) stamp(p, 6);               // diagnostic: the first group's rows are there
+        if (CTC_DIAG(p) < 0 && g == 0) stamp(p, 6);               // diagnostic: the first group's rows are there
         // raw rows -> tile, labels' logits back
         x.to_tile(trow, i16);
         lds_order();
@@ -627,7 +633,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         // nothing of the next group may be scheduled in front of this publication: the chains wait
         // for it, and the next group's first instruction waits for loads that are still in flight
         __builtin_amdgcn_sched_barrier(0);
-        if (p.stop < 0) stamp(p, 8 + g);                     // diagnostic: group g published
+        if (CTC_DIAG(p) < 0) stamp(p, 8 + g);                     // diagnostic: group g published
     }
     __builtin_amdgcn_s_setprio(0);
     stamp(p, 2);
@@ -658,7 +664,10 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             }
             lds_order();
         }
-        if (p.stop < 0) stamp(p, 3 + (G - 1 - g));
+#ifdef CTC_AMD_FAULT_INJECT                                  // tests/test_status.py: sample 1's workers "starve"
+        if (b == 1) starved = true;
+#endif
+        if (CTC_DIAG(p) < 0) stamp(p, 3 + (G - 1 - g));
         int occn[2] = {0, 0}, max_occ = 0;
         if (need_a > 0) {                                    // (wave-uniform; a group without live rows adds nothing)
             occn[0] = own[0] ? sm.occ[lst[0]] : 0;
@@ -690,7 +699,10 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         float tot = z[0] + z[1];
         row16_allsum(tot);
         float rinv = (live && tot > 0.f) ? gsc * __builtin_amdgcn_rcpf(tot) : 0.f;
-        if (starved) rinv = __builtin_nanf("");              // never observed; loud if a hand-off were broken
+        if (starved) {                                       // never observed; loud if a hand-off were broken
+            rinv = __builtin_nanf("");
+            raise_status(p.counter, kStatusNoblankStarved);
+        }
         // class occupancy of the four rows: zero the tile, scatter the scaled posteriors
         Row::zero_tile(trow, i16);
         lds_order();

@@ -103,6 +103,7 @@ __device__ __forceinline__ cell_t xr_chain_sync(const NoblankParams &p, const ce
     typedef const volatile __attribute__((address_space(3))) int lds_cvint;
     const int *cp = cnt + (lane < kPipeWorkers ? lane : 0);
     int seen = *(lds_cvint *)cp;
+    bool starved = false;                                    // a bounded wait ran out: NaN instead of a plausible number
     auto wait_upto = [&](int i_last) {
         const int q = pos0 + (i_last < Tb ? i_last : Tb - 1);
         int need = 0;
@@ -110,7 +111,8 @@ __device__ __forceinline__ cell_t xr_chain_sync(const NoblankParams &p, const ce
         else if (q >= lane) need = 2 * ((q - lane) / kPipeWorkers) + (FWD ? 1 : 2);
         if (lane >= kPipeWorkers) need = 0;
         int spins = 0;
-        while (__builtin_amdgcn_ballot_w64(seen < need) != 0 && ++spins < kSpinLimit) {
+        while (__builtin_amdgcn_ballot_w64(seen < need) != 0) {
+            if (++spins >= kSpinLimit) { starved = true; break; }
             __builtin_amdgcn_s_sleep(1);
             seen = *(lds_cvint *)cp;
         }
@@ -165,7 +167,7 @@ __device__ __forceinline__ cell_t xr_chain_sync(const NoblankParams &p, const ce
         lds_order();
         *prog = i;
         wait_upto(i + kBlockSteps - 1 + kPrefetch);
-        if (p.stop < 0) stamp(p, 2 + i / kBlockSteps);       // diagnostic: block starts -> slots 2..10
+        if (CTC_DIAG(p) < 0) stamp(p, 2 + i / kBlockSteps);       // diagnostic: block starts -> slots 2..10
 #pragma unroll
         for (int j = 0; j < kBlockSteps; ++j) {
             const cell_t e = ring[j % kPrefetch];
@@ -188,6 +190,10 @@ __device__ __forceinline__ cell_t xr_chain_sync(const NoblankParams &p, const ce
     lds_order();
     *prog = Tb;
     __builtin_amdgcn_s_setprio(0);
+    if (starved) {
+        raise_status(p.counter, kStatusNoblankStarved);
+        return make_cell(__builtin_nanf(""), 0);
+    }
     return make_cell(m, k);
 }
 
@@ -247,7 +253,8 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_xr_kernel(Nobl
                 // nll = -log alpha[T_b-1, L_b-1] (NoBlankCTC.py:58-68,139) from lane L-1
                 const float am = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a.x), L - 1));
                 const int ak = __builtin_amdgcn_readlane(cell_k(a), L - 1);
-                const float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(ak - kXrBias)) * kLn2 : -kNeg;
+                float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(ak - kXrBias)) * kLn2 : -kNeg;
+                if (am != am) nll = am;                      // starved hand-off
                 publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
                                    [](float x, int) { return x; });
             } else if (p.grad) {
@@ -342,9 +349,13 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_xr_kernel(Nobl
         lds_order();
         if (lane == 0) sm.dummy[7] = 1.0f;
     }
+    bool starved = false;                                    // a bounded wait ran out: NaN gradient rows, status raised
     {
         int spins = 0;
-        while (lds_now(sm.dummy + 7) == 0.f && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(4);
+        while (lds_now(sm.dummy + 7) == 0.f) {
+            if (++spins >= kSpinLimit) { starved = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
         lds_order();
     }
     int first[CH];
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_xr_kernel(Nobl
     const bool any_dup = __builtin_amdgcn_ballot_w64(my_dup != 0) != 0;
     const int Tlive = Tb;
     const int lcl = lane < p.SP ? lane : 0;
-    const float gsc = p.grad_scale;
+    const float gsc0 = p.grad_scale;
     int shiftk = 0;                                          // shared exponent shift of the posterior rows
     bool have_shift = false;
     const bool pair = p.SP <= 32;
@@ -383,12 +394,15 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_xr_kernel(Nobl
         }
         if (need_a > 0) {
             int spins = 0;
-            while ((*(lds_cvint *)(sm.cnt + kPipeWorkers) < need_a || *(lds_cvint *)(sm.cnt + kPipeWorkers + 1) < need_b) &&
-                   ++spins < kSpinLimit)
+            while (*(lds_cvint *)(sm.cnt + kPipeWorkers) < need_a || *(lds_cvint *)(sm.cnt + kPipeWorkers + 1) < need_b) {
+                if (++spins >= kSpinLimit) { starved = true; break; }
                 __builtin_amdgcn_s_sleep(8);
+            }
             lds_order();
         }
-        if (p.stop < 0) stamp(p, 3 + (2 - gq));
+        if (starved) raise_status(p.counter, kStatusNoblankStarved);
+        const float gsc = starved ? __builtin_nanf("") : gsc0;
+        if (CTC_DIAG(p) < 0) stamp(p, 3 + (2 - gq));
         // gamma_t(l) = alpha_t(l) beta_t(l) / sum_l' (...): products of mantissas, exponents added;
         // every row's total is the same number P(x, labels) up to rounding, so the exponent of
         // the largest cell of the first (middle) group shifts all later rows into range too.

@@ -57,6 +57,45 @@ def _workspace(variant, T, B, C, S, device, stream=None):
     return held[-1]
 
 
+STATUS_BITS = {1: "no-blank launch", 2: "binary launch", 4: "blank-CTC launch"}
+
+
+def workspace_status(device=None, clear=True):
+    """OR of the status words of this process's hidden workspaces on `device` (all devices if None).
+
+    0 = every in-launch hand-off completed.  A non-zero value means a bounded wait ran out in some
+    launch since the last clear (the affected outputs were filled with NaN, include/ctc_amd.h);
+    synchronises the workspaces' streams."""
+    import ctypes
+    lib = _lib.load()
+    total = 0
+    for (dev_index, stream, _variant), held in list(_workspaces.items()):
+        if device is not None and torch.device(device).index not in (None, dev_index):
+            continue
+        with torch.cuda.device(dev_index):
+            for ws in held:
+                word = ctypes.c_uint(0)
+                rc = lib.ctc_amd_workspace_status(ws.data_ptr(), int(bool(clear)), stream, ctypes.byref(word))
+                if rc:
+                    _lib.check(rc, "ctc_amd_workspace_status")
+                total |= word.value
+    return total
+
+
+def check_status(device=None):
+    """Raise CtcAmdError if any launch since the last check reported a starved hand-off."""
+    st = workspace_status(device, clear=True)
+    if st:
+        what = ", ".join(v for k, v in STATUS_BITS.items() if st & k)
+        raise _lib.CtcAmdError("ctc_amd: an in-launch wait ran out (%s, status %d): the outputs of that call "
+                               "carry NaN -- see include/ctc_amd.h, ctc_amd_workspace_status" % (what, st))
+
+
+def set_blank_schedule(mode):
+    """-1: the library chooses (default); 1 / 0: force / forbid the persistent blank-CTC launch."""
+    _lib.check(_lib.load().ctc_amd_blank_set_schedule(int(mode)), "ctc_amd_blank_set_schedule")
+
+
 class _NullCtx:
     def __enter__(self):
         return self
@@ -177,6 +216,8 @@ def _launch(variant, x, targets, in_len, tgt_len, want_grad, batch_total, blank=
                 op, op + 4 * B, gp, ws.data_ptr(), stream)
             if rc:
                 _lib.check(rc, "ctc_amd_blank_loss_grad")
+    if _VALIDATE:
+        check_status(dev)
     return out[B], out[:B], grad
 
 

@@ -15,7 +15,8 @@
  *  - inputs are read-only; outputs are fully overwritten (grad rows t >= T_b get 0);
  *  - the caller owns all memory.  `workspace` must hold ctc_amd_workspace_bytes(...)
  *    bytes, be zero-filled ONCE when allocated, and not be shared by launches that
- *    may run concurrently (one workspace per stream);
+ *    may run concurrently (one workspace per stream); bytes [8,12) are the status word
+ *    (ctc_amd_workspace_status);
  *  - return value: 0 on success, a hipError_t (> 0) from the launch, or one of the
  *    negative CTC_AMD_ERR_* codes; ctc_amd_error_string() describes any of them.
  */
@@ -91,7 +92,7 @@ int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_t stride_b,
  * launch of at most one workgroup per CU in which workgroups wait for each other (bounded: a wait
  * that runs out poisons nll / grad with NaN instead of hanging).  Kernels of other streams on the
  * same device can only delay it; the workspace belongs to one call in flight at a time, as for every
- * entry point.  CTC_AMD_BLANK_FUSED=1 / 0 in the environment forces / forbids that schedule.
+ * entry point.  ctc_amd_blank_set_schedule() forces / forbids that schedule.
  */
 int ctc_amd_blank_loss_grad(const float *log_probs, int64_t stride_t, int64_t stride_b,
                             const void *targets, int targets_i64,
@@ -100,6 +101,19 @@ int ctc_amd_blank_loss_grad(const float *log_probs, int64_t stride_t, int64_t st
                             float loss_scale, float grad_scale,
                             float *nll, float *loss, float *grad,
                             void *workspace, void *stream);
+
+/* Schedule of the long-sequence blank-CTC path: -1 = the library's own choice (default), 1 / 0 = force /
+ * forbid the single persistent launch (tests and measurements; process-wide, thread-safe).  The
+ * environment variable CTC_AMD_BLANK_FUSED=1 / 0, read ONCE at first use, sets the initial value. */
+int ctc_amd_blank_set_schedule(int mode);
+
+/* In-launch hand-offs between waves / workgroups wait with a bound (~1 s).  A wait that runs out never
+ * yields a plausible number: the outputs that could not be produced are filled with NaN (nll of the
+ * sample, the loss, the sample's gradient rows) and a bit is ORed into the workspace's STATUS word, which
+ * stays set until cleared here.  Reads the word (synchronising `stream`); clear != 0 resets it.
+ * Bits: 1 no-blank, 2 binary, 4 blank-CTC launch starved.  Never observed outside fault-injection builds;
+ * the persistent blank-CTC launch is the one place where another process's kernels could cause it. */
+int ctc_amd_workspace_status(void *workspace, int clear, void *stream, unsigned *status_host);
 
 /* backward of the autograd.Function: grad[i] *= *grad_out (a device scalar, the
  * upstream gradient of the 0-dim loss).  Every workgroup reads *grad_out and exits

@@ -25,6 +25,23 @@ def dev():
     return torch.device("cuda:0")
 
 
+def _schedule(monkeypatch, mode):
+    """blank-CTC schedule for this test only: 1 / 0 force / forbid the persistent launch, -1 the library's choice"""
+    import ctc_amd
+    ctc_amd.set_blank_schedule(mode)
+    request_undo.append(lambda: ctc_amd.set_blank_schedule(-1))
+
+
+request_undo = []
+
+
+@pytest.fixture(autouse=True)
+def _restore_schedule():
+    yield
+    while request_undo:
+        request_undo.pop()()
+
+
 def run_hip(fn, x, tg, il, tl, dev, lens_on_gpu=True, **kw):
     xd = torch.as_tensor(x, dtype=torch.float32).to(dev).requires_grad_(True)
     tgd = torch.as_tensor(tg).to(dev)
@@ -239,9 +256,9 @@ def test_blank_vs_torch_cpu(dev, shape, var_T, schedule, monkeypatch):
     if schedule == "persistent":
         if T < 128:
             pytest.skip("the persistent launch needs T >= 128")
-        monkeypatch.setenv("CTC_AMD_BLANK_FUSED", "1")
+        _schedule(monkeypatch, 1)
     else:
-        monkeypatch.delenv("CTC_AMD_BLANK_FUSED", raising=False)
+        _schedule(monkeypatch, -1)
     lp, tgt, Tb, L = synth_blank(sum(shape), T, B, C, S, var_T=var_T)
     if not var_T:
         tgt[0, 1:4] = tgt[0, 0]                   # repeated labels force blanks in between
@@ -268,7 +285,7 @@ def test_blank_fused_schedule_edge_cases(dev, schedule, monkeypatch):
     """the single persistent launch (and the three launches): ragged lengths, a one-frame sample, an empty
     target, a sample without any alignment and an empty input in one batch, against the float64 oracle"""
     import ctc_amd
-    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", schedule)
+    _schedule(monkeypatch, int(schedule))
     T, B, C, S = 160, 7, 36, 20
     lp, tgt, Tb, L = synth_blank(77, T, B, C, S, var_T=True)
     Tb[0], L[0] = T, S
@@ -300,7 +317,7 @@ def test_blank_nonzero_blank_index_and_wide_rows(dev, shape, monkeypatch):  # to
     """blank = C-1 instead of 0 (torch CPU as the comparator), targets drawn from the other classes"""
     import ctc_amd
     T, B, C, S = shape
-    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", "1")
+    _schedule(monkeypatch, 1)
     lp, tgt, Tb, L = synth_blank(11 + T, T, B, C, S, var_T=True)
     blank = C - 1
     tgt = (tgt - 1).clamp(min=0)                       # synth_blank draws from 1..C-1: shift to 0..C-2
@@ -326,9 +343,9 @@ def test_blank_persistent_launch_is_the_default_for_config5_like_batches(dev, mo
     T, B, C, S = 260, 32, 512, 100
     lp, tgt, Tb, L = synth_blank(5, T, B, C, S, var_T=True)
     ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64, threads=8)
-    monkeypatch.delenv("CTC_AMD_BLANK_FUSED", raising=False)
+    _schedule(monkeypatch, -1)
     auto = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
-    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", "0")
+    _schedule(monkeypatch, 0)
     three = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
     for r in (auto, three):
         assert (np.abs(r["nll"] - ref["nll"]) <= 1e-5 * np.maximum(1, np.abs(ref["nll"]))).all()
@@ -568,7 +585,7 @@ def test_blank_config5_full_size(dev, schedule, monkeypatch):
     against the float64 oracle.  The bar is north_star's 1e-4 on the PER-SAMPLE gradient (the batch mean
     carries 1/(B L_b)): the measured error is printed."""
     import ctc_amd
-    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", schedule)
+    _schedule(monkeypatch, int(schedule))
     T, B, C, S = 2000, 64, 1000, 100
     lp, tgt, Tb, L = synth_blank(0, T, B, C, S)
     ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64, threads=16)
@@ -680,7 +697,7 @@ def test_blank_persistent_launch_beside_a_busy_stream(dev, monkeypatch):
     """The persistent blank-CTC launch (workgroups waiting for each other) while ANOTHER stream keeps the GPU
     busy with a long kernel: it may be delayed, it must not hang or return poisoned values."""
     import ctc_amd
-    monkeypatch.setenv("CTC_AMD_BLANK_FUSED", "1")
+    _schedule(monkeypatch, 1)
     T, B, C, S = 512, 40, 400, 60
     lp, tgt, Tb, L = synth_blank(5, T, B, C, S)
     ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64, threads=8)

@@ -5,6 +5,15 @@ Slots: 0 worker 0 enters; 1+k alpha chain of sample 0 at step 256 k; 10 that cha
 import os
 import sys
 
+ROOT_ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT_)
+from ctc_amd import build as _build  # noqa: E402
+if "CTC_AMD_LIB" not in os.environ:                           # diagnostics live in the -DCTC_AMD_DIAGNOSTICS build only
+    _diag = os.path.join(ROOT_, "ctc_amd", "lib", "libctc_amd_diag.so")
+    os.environ["CTC_AMD_LIB"] = _diag if os.path.exists(_diag) else _build.build_diag()
+import os
+import sys
+
 import numpy as np
 import torch
 

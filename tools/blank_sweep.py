@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: blank-CTC loss+gradient call time over sequence lengths, for choosing between the persistent
-launch and the three launches: each length is timed with CTC_AMD_BLANK_FUSED=1 and =0.  Not part of the product path.
+launch and the three launches: each length is timed with ctc_amd_blank_set_schedule(1) and (0).  Not part of the product path.
 usage: tools/blank_sweep.py [--shape B,C,S] T..."""
 import os
 import sys
@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402
+import ctc_amd  # noqa: E402
 
 argv = sys.argv[1:]
 B, C, S = 64, 1000, 100
@@ -19,7 +20,7 @@ Ts = [int(v) for v in argv] or [128, 256, 512, 1000, 2000]
 
 
 def timed(T):
-    bench.WORKLOADS["blank"] = ("sweep", T, C, S, B)
+    bench.WORKLOADS["blank"] = ("sweep", T, C, S, B, "sweep")
     wl = bench.Workload("blank", B, B, torch.device("cuda:0"), 0)
     ws = wl.new_workspace()
     loss = torch.zeros(4, device="cuda")
@@ -39,6 +40,7 @@ def timed(T):
 for T in Ts:
     t = {}
     for mode in ("1", "0"):
-        os.environ["CTC_AMD_BLANK_FUSED"] = mode       # read by the library on every call
+        ctc_amd.set_blank_schedule(int(mode))
         t[mode] = timed(T)
+ctc_amd.set_blank_schedule(-1)
     print("B=%d C=%d S=%d T=%5d: persistent launch %8.1f us, three launches %8.1f us per call" % (B, C, S, T, t["1"], t["0"]))

@@ -1,5 +1,14 @@
 #!/usr/bin/env python3
 """Diagnostic: the lattice chain of noblank_r16.hpp alone (all rows pre-published), cycles per step."""
+import os
+import sys
+
+ROOT_ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT_)
+from ctc_amd import build as _build  # noqa: E402
+if "CTC_AMD_LIB" not in os.environ:                           # diagnostics live in the -DCTC_AMD_DIAGNOSTICS build only
+    _diag = os.path.join(ROOT_, "ctc_amd", "lib", "libctc_amd_diag.so")
+    os.environ["CTC_AMD_LIB"] = _diag if os.path.exists(_diag) else _build.build_diag()
 import ctypes
 import os
 import sys
