@@ -3,14 +3,16 @@
 Slots: 0 worker 0 enters; 1+k alpha chain of sample 0 at step 256 k; 10 that chain done;
 11 worker 0 done gathering; 12/13/14 worker 0 / last / middle worker done.  Not part of the product path."""
 import os
+import subprocess
 import sys
 
 ROOT_ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT_)
-from ctc_amd import build as _build  # noqa: E402
 if "CTC_AMD_LIB" not in os.environ:                           # diagnostics live in the -DCTC_AMD_DIAGNOSTICS build only
-    _diag = os.path.join(ROOT_, "ctc_amd", "lib", "libctc_amd_diag.so")
-    os.environ["CTC_AMD_LIB"] = _diag if os.path.exists(_diag) else _build.build_diag()
+    _diag = os.path.join(ROOT_, "ctc_amd", "lib", "libctc_amd_diag.so")   # (set BEFORE ctc_amd is imported)
+    if not os.path.exists(_diag):
+        subprocess.check_call([sys.executable, "-m", "ctc_amd.build", "--diag"], cwd=ROOT_, stdout=subprocess.DEVNULL)
+    os.environ["CTC_AMD_LIB"] = _diag
 import os
 import sys
 
