@@ -1,4 +1,5 @@
 // C-ABI entry points that are not tied to one kernel file (include/ctc_amd.h).
+#include "common.hpp"
 #include "launch.hpp"
 
 namespace ctc {
@@ -20,7 +21,7 @@ extern "C" const char *ctc_amd_error_string(int code)
 
 extern "C" size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int S)
 {
-    // [0,256): arrival counter of the in-launch batch reduction (+ padding)
+    // [0,256): header -- arrival counter / packed batch sum of the in-launch reduction, status word, diagnostics
     size_t bytes = 256;
     if (variant == CTC_AMD_BLANK) {
         // emissions, alpha, beta lattices [B][T][NSP] fp32 + three [B][NSP] int state tables + [B] int2 lengths
@@ -31,6 +32,8 @@ extern "C" size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int 
         bytes += 3 * (size_t)B * (size_t)T * nsp * sizeof(float) + 3 * (size_t)B * nsp * sizeof(int) +
                  (2 * (((size_t)B + 63) & ~(size_t)63) + (size_t)ctc::blank_sync_ints(T, B)) * sizeof(int);
     }
+    // no-blank / binary: the list of samples whose nll does not fit the packed batch sum (common.hpp)
+    if (variant == CTC_AMD_NOBLANK || variant == CTC_AMD_BINARY) bytes += ctc::acc_list_bytes(B);
     if (variant == CTC_AMD_NOBLANK) bytes += ctc::noblank_extra_workspace(T, B, C, S);   // 0 while T x S fits in LDS
     return bytes;
 }

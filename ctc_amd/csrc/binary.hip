@@ -151,8 +151,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_fused_kernel(BinaryParams 
 
     const float nll = ok ? -sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;
     if (w == kBinWaves - 1)
-        publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
-                           [](float v, int) { return v; });
+        publish_and_reduce_sum(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
     if (!p.grad) return;
 
     // P3: posteriors of this wave's rows, then the gradient rows
@@ -343,8 +342,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
                 nll = __builtin_nanf("");
                 raise_status(p.counter, kStatusBinaryStarved);
             }
-            publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
-                               [](float x, int) { return x; });
+            publish_and_reduce_sum(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
         }
         if (!p.grad) return;
     }

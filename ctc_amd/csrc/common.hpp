@@ -318,4 +318,67 @@ __device__ __forceinline__ void publish_and_reduce(float value, int b, int B, fl
 #endif
 }
 
+// Batch sum of the per-sample values without the three dependent round trips of publish_and_reduce
+// (nll store -> acknowledgement -> ticket -> last arriver reads every nll -> loss), which cost the
+// kernel its tail through queues full of gradient stores (config 2: 13.2 us with, 12.1 us without).
+// Every workgroup makes ONE returning 64-bit atomic add to a packed word
+//     [63:52] arrivals   [51:40] arrivals that did not fit   [39:0] sum of value * 2^16 (fixed point);
+// integer adds commute, so whoever completes a word holds its exact sum: bitwise the same from run to
+// run, exact to 2^-17 per sample.  Atomics on ONE word are served at ~90 per us (256 workgroups
+// finishing together wait 2.8 us for each other), so the words are SHARDED: sample b adds to shard
+// b % 16, the workgroup that completes a shard adds the shard's word to the top word, and the one that
+// completes the top word writes the loss.  The nll output is a write-through store nobody waits for.
+// A value that does not fit (value * B >= 2^24, negative, NaN, inf: the infeasible sentinel 1e13, a
+// starved hand-off) takes the slow way for ITSELF only -- store, acknowledgement, its index into a
+// list, acknowledgement, then the packed add counting it as "did not fit" -- and the finisher adds those
+// from memory (in double).  B > 4095: the ticket form.
+// Workspace: bytes [16,24) top word, [24,28) list length, [256,512) shard words, [512, 512 + 4 B) the list.
+constexpr int kAccFracBits = 16, kAccMaxB = 4095, kAccShards = 16;
+__host__ __device__ inline size_t acc_list_bytes(int B) { return 256 + (((size_t)4 * B + 255) & ~(size_t)255); }
+__device__ __forceinline__ void publish_and_reduce_sum(float value, int b, int B, float *nll, float *loss,
+                                                       float loss_scale, unsigned *counter)
+{
+    if (B > kAccMaxB) {
+        publish_and_reduce(value, b, B, nll, loss, loss_scale, counter, [](float x, int) { return x; });
+        return;
+    }
+    if (lane_id() != 0) return;
+    unsigned long long *top = reinterpret_cast<unsigned long long *>(counter + 4);
+    unsigned long long *shards = reinterpret_cast<unsigned long long *>(counter + 64);
+    unsigned *nlist = counter + 6, *list = counter + 128;
+    __hip_atomic_store(&nll[b], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long add = 1ull << 52;
+    if (value >= 0.f && value * (float)B < 16777216.f) {
+        add += (unsigned long long)__double2ull_rn((double)value * (double)(1 << kAccFracBits));
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this value is in memory ...
+        const unsigned slot = __hip_atomic_fetch_add(nlist, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&list[slot], (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... and on the list before it is counted
+        add += 1ull << 40;
+    }
+    const int sh = b % kAccShards;
+    const int members = (B - sh + kAccShards - 1) / kAccShards;          // samples b' < B with b' % 16 == sh
+    unsigned long long *word = shards + 2 * sh;                          // 16-byte pitch
+    unsigned long long old = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CTC_X_NORETURN
+    return;
+#endif
+    if ((old >> 52) != (unsigned long long)(members - 1)) return;
+    add += old;                                                          // the shard, complete
+    __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __hip_atomic_fetch_add(top, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((old >> 52) + (add >> 52) != (unsigned long long)B) return;
+    const unsigned long long tot = old + add;
+    double s = (double)(tot & ((1ull << 40) - 1)) * (1.0 / (double)(1 << kAccFracBits));
+    const unsigned nsp = (unsigned)(tot >> 40) & 0xfffu;
+    for (unsigned i = 0; i < nsp; ++i) {
+        const unsigned bb = __hip_atomic_load(&list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s += (double)__hip_atomic_load(&nll[bb < (unsigned)B ? bb : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    loss[0] = (float)(s * (double)loss_scale);
+    __hip_atomic_store(top, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(nlist, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace ctc

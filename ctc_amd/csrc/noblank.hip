@@ -38,7 +38,7 @@ struct NoblankParams {
     float loss_scale, grad_scale;
     float *nll, *loss, *grad;
     float *gamma;               // optional [B][T][S] posteriors output (ctc_amd_noblank_posteriors)
-    float *lattice;             // global-memory lattice slabs (workspace + 256 B) when T x S exceeds LDS
+    float *lattice;             // global-memory lattice slabs (workspace, behind header and list) when T x S exceeds LDS
     int64_t slab;               // floats per sample in `lattice`
     unsigned *counter;
 };
@@ -322,8 +322,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
     // published by the LAST wave: it owns the fewest rows (none when T <= 150), so the
     // store-drain + ticket round trip stays off the other waves' critical path
     if (w == kWaves - 1)
-        publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
-                           [](float v, int) { return v; });
+        publish_and_reduce_sum(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
     if (!p.grad && !p.gamma) return;
 
     // P3
@@ -448,7 +447,7 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     if (smem > kMaxLds) {                                    // long sequence: lattice in the workspace
         smem = noblank_tables_bytes(p.SP, C);
         if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
-        p.lattice = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256);
+        p.lattice = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + acc_list_bytes(B));
         p.slab = (int64_t)noblank_lattice_floats(T, p.SP);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -567,7 +566,7 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
     if (smem > kMaxLds) {
         smem = noblank_tables_bytes(p.SP, C);
         if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
-        p.lattice = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256);
+        p.lattice = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + acc_list_bytes(B));
         p.slab = (int64_t)noblank_lattice_floats(T, p.SP);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -217,16 +217,14 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
                 stamp(p, 2);
                 // nll = -alpha[T_b-1, L_b-1] (NoBlankCTC.py:58-68,139) straight from lane L-1
                 const float nll = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), L - 1));
-                publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
-                                   [](float x, int) { return x; });
+                publish_and_reduce_sum(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
             } else if (p.grad) {                             // w == kChainB
                 if (rot) lattice_chain_sync<false, true>(p, sm.em, sm.be, sm.dummy, sm.cnt, p.T, Tb, L, p.SP);
                 else lattice_chain_sync<false, false>(p, sm.em, sm.be, sm.dummy, sm.cnt, p.T, Tb, L, p.SP);
                 stamp(p, 2);
             }
         } else if (w == 0) {
-            publish_and_reduce(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
-                               [](float x, int) { return x; });
+            publish_and_reduce_sum(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
         }
         stamp(p, 7);
         return;

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 
     if (Tb == 0) {                                           // no alignment exists: nll = 1e13, zero gradient
         if (w == 0)
-            publish_and_reduce(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
+            publish_and_reduce_sum(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
         if (u >= 0 && p.grad) {
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             const float am = a.x;
             float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(cell_k(a) - kXrBias)) * kLn2 : -kNeg;
             if (am != am) nll = am;                          // starved hand-off: NaN, not a plausible number
-            publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter, [](float x, int) { return x; });
+            publish_and_reduce_sum(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
             if (CTC_DIAG(p) == -50 && lane == 0) {                // diagnostic: when the alpha wave (loss ticket) is done
                 const int bid = blockIdx.x, nb = gridDim.x;
                 const int slot = bid == 0 ? 6 : bid == nb / 2 ? 7 : bid == nb - 1 ? 8 : -1;

@@ -255,15 +255,13 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_xr_kernel(Nobl
                 const int ak = __builtin_amdgcn_readlane(cell_k(a), L - 1);
                 float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(ak - kXrBias)) * kLn2 : -kNeg;
                 if (am != am) nll = am;                      // starved hand-off
-                publish_and_reduce(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
-                                   [](float x, int) { return x; });
+                publish_and_reduce_sum(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
             } else if (p.grad) {
                 xr_chain_sync<false>(p, sm.em, sm.be, spare, sm.cnt, p.T, Tb, L, p.SP);
                 stamp(p, 11);
             }
         } else if (w == 0) {
-            publish_and_reduce(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter,
-                               [](float x, int) { return x; });
+            publish_and_reduce_sum(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
         }
         return;
     }

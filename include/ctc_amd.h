@@ -43,8 +43,9 @@ extern "C" {
 int ctc_amd_abi_version(void);
 const char *ctc_amd_error_string(int code);
 
-/* Bytes of device workspace a call of this shape needs (>= 256).  No-blank lattices that do
- * not fit in LDS (long sequences) and the blank-CTC lattice live in this workspace. */
+/* Bytes of device workspace a call of this shape needs (>= 256: a header with the in-launch batch
+ * reduction's words and the status word, then per-variant areas).  No-blank lattices that do not fit
+ * in LDS (long sequences) and the blank-CTC lattice live in this workspace. */
 size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int S);
 
 /* NoBlankCTC.forward (NoBlankCTC.py:129-141) + the gradient autograd would produce
