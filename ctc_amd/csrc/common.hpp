@@ -42,6 +42,19 @@ __device__ __forceinline__ void through_store(wt_f4 *p, wt_f4 v)
 {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
+// gradient store of a launch: write-through while logits + gradient fit the memory-side cache, non-temporal
+// beyond it (r16 kernel, T = 150, C = 158, us per launch, write-through / non-temporal: B = 512 25.9 / 30.6,
+// 1024 49.7 / 54.6, 1536 83.9 / 78.2, 2048 133.5 / 101.3)
+template <bool NT, typename V>
+__device__ __forceinline__ void grad_store(V *p, V v)
+{
+    if (NT) {
+        typedef V __attribute__((aligned(8))) VA;
+        __builtin_nontemporal_store(v, reinterpret_cast<VA *>(p));
+    } else {
+        through_store(p, v);
+    }
+}
 
 // Workspace word 2 (bytes [8,12)): STATUS.  A bounded in-kernel wait that ran out ORs its bit in here
 // (and poisons the outputs it could not produce with NaN); nothing in the kernels ever clears it --

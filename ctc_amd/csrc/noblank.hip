@@ -463,26 +463,28 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
         const bool dual = B > cus && 2 * smem <= kMaxLds;    // more samples than CUs: two workgroups per CU
         // lean four-rows-per-wave workers (noblank_r16.hpp): 8-byte aligned rows, S <= 31
         static const bool no_r16 = diag_env("CTC_AMD_NOR16") != 0;
-        static const bool force_r16 = diag_env("CTC_AMD_R16_ALWAYS") != 0;
         const bool aligned = C % 2 == 0 && stride_t % 2 == 0 && stride_b % 2 == 0 &&
                              reinterpret_cast<uintptr_t>(x) % 8 == 0 && reinterpret_cast<uintptr_t>(grad) % 8 == 0;
         const size_t rsmem = r16_smem_bytes(T, p.SP, C);
+        // lean four-rows-per-wave workers (noblank_r16.hpp): 8-byte aligned rows, S <= 31.  Also with more
+        // samples than CUs: one workgroup per CU at a time still beats two of the one-row-per-wave kind
+        // (T = 150, C = 158, us per launch r16 / xr: B = 384 22.5 / 27.7, 512 25.9 / 31.2, 768 37.6 / 45.2,
+        // 1024 49.7 / 56.6, 1536 78.2 / 78.5, 2048 101.3 / 99.7)
         int n4 = 0, n2 = 0;
-        if (!no_r16 && aligned && r16_shape(C, n4, n2) && p.SP <= 31 && rsmem <= kMaxLds && (!dual || force_r16)) {
+        if (!no_r16 && aligned && r16_shape(C, n4, n2) && p.SP <= 31 && rsmem <= kMaxLds) {
+            // logits + gradient beyond the memory-side cache (256 MB): non-temporal gradient stores
+            const bool nt = (size_t)8 * T * B * C > ((size_t)230 << 20);
+#define CTC_R16_CASE(K, A, Bq)                                                                          \
+            case K: return nt ? launch<noblank_r16_kernel<A, Bq, true>>(grid, block, rsmem, s, p)         \
+                              : launch<noblank_r16_kernel<A, Bq, false>>(grid, block, rsmem, s, p);
             switch (4 * n4 + n2) {
-                case 1: return launch<noblank_r16_kernel<0, 1>>(grid, block, rsmem, s, p);
-                case 2: return launch<noblank_r16_kernel<0, 2>>(grid, block, rsmem, s, p);
-                case 4: return launch<noblank_r16_kernel<1, 0>>(grid, block, rsmem, s, p);
-                case 5: return launch<noblank_r16_kernel<1, 1>>(grid, block, rsmem, s, p);
-                case 6: return launch<noblank_r16_kernel<1, 2>>(grid, block, rsmem, s, p);
-                case 8: return launch<noblank_r16_kernel<2, 0>>(grid, block, rsmem, s, p);
-                case 9: return launch<noblank_r16_kernel<2, 1>>(grid, block, rsmem, s, p);
-                case 10: return launch<noblank_r16_kernel<2, 2>>(grid, block, rsmem, s, p);
-                case 12: return launch<noblank_r16_kernel<3, 0>>(grid, block, rsmem, s, p);
-                case 13: return launch<noblank_r16_kernel<3, 1>>(grid, block, rsmem, s, p);
-                case 14: return launch<noblank_r16_kernel<3, 2>>(grid, block, rsmem, s, p);
-                default: return launch<noblank_r16_kernel<4, 0>>(grid, block, rsmem, s, p);
+                CTC_R16_CASE(1, 0, 1) CTC_R16_CASE(2, 0, 2) CTC_R16_CASE(4, 1, 0) CTC_R16_CASE(5, 1, 1)
+                CTC_R16_CASE(6, 1, 2) CTC_R16_CASE(8, 2, 0) CTC_R16_CASE(9, 2, 1) CTC_R16_CASE(10, 2, 2)
+                CTC_R16_CASE(12, 3, 0) CTC_R16_CASE(13, 3, 1) CTC_R16_CASE(14, 3, 2)
+                default: return nt ? launch<noblank_r16_kernel<4, 0, true>>(grid, block, rsmem, s, p)
+                                   : launch<noblank_r16_kernel<4, 0, false>>(grid, block, rsmem, s, p);
             }
+#undef CTC_R16_CASE
         }
         if (!no_xr && xsmem <= kMaxLds && (!dual || 2 * xsmem <= kMaxLds)) {
             if (dual) {

@@ -403,6 +403,7 @@ struct R16Row {
         for (int k = 0; k < N2; ++k) *reinterpret_cast<f2_t *>(trow + off2(k, i16)) = z2;
     }
     // grad row = x * rs - occupancy (from the tile), written through; `g` = start of the row in grad
+    template <bool NT>
     __device__ __forceinline__ void store_grad(float *g, const float *trow, int i16, float rs, bool col_ok) const
     {
 #pragma unroll
@@ -413,7 +414,7 @@ struct R16Row {
             v.y = __builtin_fmaf(a[j].y, rs, -o.y);
             v.z = __builtin_fmaf(a[j].z, rs, -o.z);
             v.w = __builtin_fmaf(a[j].w, rs, -o.w);
-            if (!(kLast4 && j == N4 - 1) || col_ok) through_store(reinterpret_cast<f4_t *>(g + off4(j, i16)), v);
+            if (!(kLast4 && j == N4 - 1) || col_ok) grad_store<NT>(reinterpret_cast<f4_t *>(g + off4(j, i16)), v);
         }
 #pragma unroll
         for (int k = 0; k < N2; ++k) {
@@ -421,19 +422,20 @@ struct R16Row {
             f2_t v;
             v.x = __builtin_fmaf(c[k].x, rs, -o.x);
             v.y = __builtin_fmaf(c[k].y, rs, -o.y);
-            if (k < N2 - 1 || col_ok) through_store(reinterpret_cast<f2_t *>(g + off2(k, i16)), v);
+            if (k < N2 - 1 || col_ok) grad_store<NT>(reinterpret_cast<f2_t *>(g + off2(k, i16)), v);
         }
     }
+    template <bool NT>
     __device__ static __forceinline__ void store_zero(float *g, int i16, bool col_ok)
     {
         const f4_t z4 = {0.f, 0.f, 0.f, 0.f};
         const f2_t z2 = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < N4; ++j)
-            if (!(kLast4 && j == N4 - 1) || col_ok) through_store(reinterpret_cast<f4_t *>(g + off4(j, i16)), z4);
+            if (!(kLast4 && j == N4 - 1) || col_ok) grad_store<NT>(reinterpret_cast<f4_t *>(g + off4(j, i16)), z4);
 #pragma unroll
         for (int k = 0; k < N2; ++k)
-            if (k < N2 - 1 || col_ok) through_store(reinterpret_cast<f2_t *>(g + off2(k, i16)), z2);
+            if (k < N2 - 1 || col_ok) grad_store<NT>(reinterpret_cast<f2_t *>(g + off2(k, i16)), z2);
     }
 };
 
@@ -449,7 +451,7 @@ static bool r16_shape(int C, int &n4, int &n2)
     return true;
 }
 
-template <int N4, int N2>
+template <int N4, int N2, bool NT>
 __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams p)
 {
     extern __shared__ float4 smem_raw[];
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         if (u >= 0 && p.grad) {
 #pragma unroll
             for (int g = 0; g < G; ++g)
-                if (tv[g] >= 0) Row::store_zero(p.grad + ((int64_t)tv[g] * p.B + b) * p.C, i16, col_ok);
+                if (tv[g] >= 0) Row::template store_zero<NT>(p.grad + ((int64_t)tv[g] * p.B + b) * p.C, i16, col_ok);
         }
         return;
     }
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         }
         lds_order();
         // dense rows: grad = softmax(x) * scale - occupancy   (dead rows: scale = occupancy = 0)
-        if (t >= 0) x.store_grad(p.grad + ((int64_t)t * p.B + b) * p.C, trow, i16, rs[g], col_ok);
+        if (t >= 0) x.template store_grad<NT>(p.grad + ((int64_t)t * p.B + b) * p.C, trow, i16, rs[g], col_ok);
         lds_order();
     }
     stamp(p, 7);
