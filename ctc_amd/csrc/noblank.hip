@@ -41,6 +41,7 @@ struct NoblankParams {
     float *lattice;             // global-memory lattice slabs (workspace, behind header and list) when T x S exceeds LDS
     int64_t slab;               // floats per sample in `lattice`
     unsigned *counter;
+    int next_round;             // > 0: B exceeds one round of workgroups -- blocks prefetch for block + next_round
 };
 
 #ifndef CTC_NOBLANK_THREADS
@@ -442,7 +443,7 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     static const bool debug_nograd = diag_env("CTC_AMD_DEBUG_NOGRAD") != 0;       // diagnostic: forward only
     if (debug_nograd) p.grad = nullptr;
     p.counter = static_cast<unsigned *>(workspace);
-    p.lattice = nullptr; p.slab = 0;
+    p.lattice = nullptr; p.slab = 0; p.next_round = 0;
     size_t smem = noblank_smem_bytes(T, p.SP, C);
     if (smem > kMaxLds) {                                    // long sequence: lattice in the workspace
         smem = noblank_tables_bytes(p.SP, C);
@@ -474,6 +475,7 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
         if (!no_r16 && aligned && r16_shape(C, n4, n2) && p.SP <= 31 && rsmem <= kMaxLds) {
             // logits + gradient beyond the memory-side cache (256 MB): non-temporal gradient stores
             const bool nt = (size_t)8 * T * B * C > ((size_t)230 << 20);
+            p.next_round = (B > cus && (size_t)T * ((C * 4 + 127) / 128) <= (size_t)kPipeWorkers * kWave) ? cus : 0;
 #define CTC_R16_CASE(K, A, Bq)                                                                          \
             case K: return nt ? launch<noblank_r16_kernel<A, Bq, true>>(grid, block, rsmem, s, p)         \
                               : launch<noblank_r16_kernel<A, Bq, false>>(grid, block, rsmem, s, p);
@@ -563,7 +565,7 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
     // the batch-mean slot of the in-launch reduction lands in a spare workspace word
     p.counter = static_cast<unsigned *>(workspace);
     p.loss = reinterpret_cast<float *>(static_cast<char *>(workspace) + 32);
-    p.lattice = nullptr; p.slab = 0;
+    p.lattice = nullptr; p.slab = 0; p.next_round = 0;
     size_t smem = noblank_smem_bytes(T, p.SP, C);
     if (smem > kMaxLds) {
         smem = noblank_tables_bytes(p.SP, C);

@@ -639,6 +639,21 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     }
     __builtin_amdgcn_s_setprio(0);
     stamp(p, 2);
+    // More samples than CUs: the workgroup that follows this one on the CU (dispatch order: block + one full
+    // round of CUs, the same XCD under round-robin placement -- speed only) will want the rows of ITS sample.
+    // One 4-byte load per lane, one 128-byte line each, pulls that sample into this XCD's L2 while the chains
+    // of this one run: 14 workers x 64 lanes cover its T rows of C floats.  The value is never used.
+    float prefetched = 0.f;
+    if (p.next_round > 0 && (int)blockIdx.x + p.next_round < p.B) {
+        const int nb = xcd_sample(blockIdx.x + p.next_round, p.B);
+        const int line = u * kWave + lane;                   // 0 .. 895
+        const int lines_per_row = (p.C * 4 + 127) / 128;
+        const int t = line / lines_per_row, c = (line - t * lines_per_row) * 32;
+        // (plain load through the compiler: it keeps the destination register reserved until the value is
+        // there; the add below is the "use", placed where the load has long returned)
+        typedef const float __attribute__((address_space(1))) gfloat;
+        if (t < p.T) prefetched = *(gfloat *)(row_ptr(p, t, nb) + (c < p.C ? c : p.C - 1));
+    }
     if (!p.grad) return;
 
     const int Tlive = Tb;
@@ -670,6 +685,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         if (b == 1) starved = true;
 #endif
         if (CTC_DIAG(p) < 0) stamp(p, 3 + (G - 1 - g));
+        if (g == G - 1) asm volatile("" ::"v"(prefetched));    // the prefetched value is "used" here (and dropped)
         int occn[2] = {0, 0}, max_occ = 0;
         if (need_a > 0) {                                    // (wave-uniform; a group without live rows adds nothing)
             occn[0] = own[0] ? sm.occ[lst[0]] : 0;
