@@ -8,7 +8,7 @@ OUT=$(realpath -m "$1"); shift
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --launch eager --steps 50 --warmup 10 --no-cpu-baseline $*"
+BENCH="python3 $REPO/bench.py --launch eager --steps 50 --warmup 10 --no-cpu-baseline --no-eager-python $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/bench_write.json" 2> "$OUT/write.err"
