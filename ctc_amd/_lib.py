@@ -19,6 +19,8 @@ PROTOTYPES = {
     "ctc_amd_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
     "ctc_amd_noblank_loss_grad": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _int,
                                          _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "ctc_amd_noblank_smoothed_loss_grad": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _int, _f32,
+                                                  _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctc_amd_binary_loss_grad": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _int, _int, _int, _int,
                                         _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctc_amd_blank_loss_grad": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int,

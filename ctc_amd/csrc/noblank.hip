@@ -42,6 +42,7 @@ struct NoblankParams {
     int64_t slab;               // floats per sample in `lattice`
     unsigned *counter;
     int next_round;             // > 0: B exceeds one round of workgroups -- blocks prefetch for block + next_round
+    float ls_a, ls_b;           // label-smoothed emission a lp[c_l] + b sum_n lp[n] (NoBlankCTC.py:100-107); 1, 0: plain
 };
 
 #ifndef CTC_NOBLANK_THREADS
@@ -417,13 +418,14 @@ static int launch_noblank(int ch, size_t smem, hipStream_t s, const NoblankParam
 
 using namespace ctc;
 
-extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64_t stride_b,
-                                         const void *labels, int labels_i64,
-                                         const int64_t *in_len, const int64_t *tgt_len,
-                                         int T, int B, int C, int S,
-                                         float loss_scale, float grad_scale,
-                                         float *nll, float *loss, float *grad,
-                                         void *workspace, void *stream)
+// label_smoothing < 0: the plain loss (every kernel); in [0, 1]: the smoothed emission, r16 kernel only
+static int noblank_run(const float *x, int64_t stride_t, int64_t stride_b,
+                       const void *labels, int labels_i64,
+                       const int64_t *in_len, const int64_t *tgt_len,
+                       int T, int B, int C, int S,
+                       float loss_scale, float grad_scale,
+                       float *nll, float *loss, float *grad,
+                       void *workspace, void *stream, float label_smoothing)
 {
     if (!x || !labels || !in_len || !tgt_len || !nll || !loss || !workspace) return CTC_AMD_ERR_BAD_ARGUMENT;
     if (T < 1 || B < 1 || C < 1 || S < 1) return CTC_AMD_ERR_BAD_ARGUMENT;
@@ -444,8 +446,12 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
     if (debug_nograd) p.grad = nullptr;
     p.counter = static_cast<unsigned *>(workspace);
     p.lattice = nullptr; p.slab = 0; p.next_round = 0;
+    const bool smooth = label_smoothing >= 0.f;
+    p.ls_b = smooth ? (1.f - label_smoothing) / (float)C : 0.f;
+    p.ls_a = smooth ? label_smoothing - p.ls_b : 1.f;
     size_t smem = noblank_smem_bytes(T, p.SP, C);
     if (smem > kMaxLds) {                                    // long sequence: lattice in the workspace
+        if (smooth) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
         smem = noblank_tables_bytes(p.SP, C);
         if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
         p.lattice = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + acc_list_bytes(B));
@@ -488,6 +494,7 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
             }
 #undef CTC_R16_CASE
         }
+        if (smooth) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;    // the smoothed emission lives in the kernel above only
         if (!no_xr && xsmem <= kMaxLds && (!dual || 2 * xsmem <= kMaxLds)) {
             if (dual) {
                 switch (ch) {
@@ -519,11 +526,37 @@ extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64
             default: return launch<noblank_pipelined_kernel<4, false>>(grid, block, smem, s, p);
         }
     }
+    if (smooth) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
     switch (K) {
         case 1: return launch_noblank<1>(ch, smem, s, p);
         case 2: return launch_noblank<2>(ch, smem, s, p);
         default: return launch_noblank<4>(ch, smem, s, p);
     }
+}
+
+extern "C" int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64_t stride_b,
+                                         const void *labels, int labels_i64,
+                                         const int64_t *in_len, const int64_t *tgt_len,
+                                         int T, int B, int C, int S,
+                                         float loss_scale, float grad_scale,
+                                         float *nll, float *loss, float *grad,
+                                         void *workspace, void *stream)
+{
+    return noblank_run(x, stride_t, stride_b, labels, labels_i64, in_len, tgt_len, T, B, C, S, loss_scale, grad_scale,
+                       nll, loss, grad, workspace, stream, -1.f);
+}
+
+extern "C" int ctc_amd_noblank_smoothed_loss_grad(const float *x, int64_t stride_t, int64_t stride_b,
+                                                  const void *labels, int labels_i64,
+                                                  const int64_t *in_len, const int64_t *tgt_len,
+                                                  int T, int B, int C, int S, float label_smoothing,
+                                                  float loss_scale, float grad_scale,
+                                                  float *nll, float *loss, float *grad,
+                                                  void *workspace, void *stream)
+{
+    if (!(label_smoothing >= 0.f && label_smoothing <= 1.f)) return CTC_AMD_ERR_BAD_ARGUMENT;
+    return noblank_run(x, stride_t, stride_b, labels, labels_i64, in_len, tgt_len, T, B, C, S, loss_scale, grad_scale,
+                       nll, loss, grad, workspace, stream, label_smoothing);
 }
 
 extern "C" int ctc_amd_scale_grad(float *grad, const float *grad_out, size_t n, void *stream)
@@ -565,7 +598,7 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
     // the batch-mean slot of the in-launch reduction lands in a spare workspace word
     p.counter = static_cast<unsigned *>(workspace);
     p.loss = reinterpret_cast<float *>(static_cast<char *>(workspace) + 32);
-    p.lattice = nullptr; p.slab = 0; p.next_round = 0;
+    p.lattice = nullptr; p.slab = 0; p.next_round = 0; p.ls_a = 1.f; p.ls_b = 0.f;
     size_t smem = noblank_smem_bytes(T, p.SP, C);
     if (smem > kMaxLds) {
         smem = noblank_tables_bytes(p.SP, C);

@@ -363,6 +363,19 @@ struct R16Row {
         for (int k = 0; k < N2; ++k) m = fmaxf(m, fmaxf(c[k].x, c[k].y) + (k == N2 - 1 ? maskv : 0.f));
         return m;
     }
+    // the lane's sum of the raw elements (`valid_last`: the last chunk lies inside the row)
+    __device__ __forceinline__ float sum(bool valid_last) const
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < N4; ++j) {
+            const float q = (a[j].x + a[j].y) + (a[j].z + a[j].w);
+            s += ((kLast4 && j == N4 - 1) && !valid_last) ? 0.f : q;
+        }
+#pragma unroll
+        for (int k = 0; k < N2; ++k) s += (k == N2 - 1 && !valid_last) ? 0.f : c[k].x + c[k].y;
+        return s;
+    }
     // x <- exp2((x + mask) log2e + mb); returns the lane's sum
     __device__ __forceinline__ float exp_sum(float maskv, float mb)
     {
@@ -403,12 +416,14 @@ struct R16Row {
         for (int k = 0; k < N2; ++k) *reinterpret_cast<f2_t *>(trow + off2(k, i16)) = z2;
     }
     // grad row = x * rs - occupancy (from the tile), written through; `g` = start of the row in grad
-    template <bool NT>
-    __device__ __forceinline__ void store_grad(float *g, const float *trow, int i16, float rs, bool col_ok) const
+    // (`cb`: a constant added to every element -- the label-smoothing term, 0 otherwise; LS selects the form)
+    template <bool NT, bool LS>
+    __device__ __forceinline__ void store_grad(float *g, const float *trow, int i16, float rs, bool col_ok, float cb) const
     {
 #pragma unroll
         for (int j = 0; j < N4; ++j) {
-            const f4_t o = *reinterpret_cast<const f4_t *>(trow + off4(j, i16));
+            f4_t o = *reinterpret_cast<const f4_t *>(trow + off4(j, i16));
+            if (LS) { o.x -= cb; o.y -= cb; o.z -= cb; o.w -= cb; }
             f4_t v;
             v.x = __builtin_fmaf(a[j].x, rs, -o.x);
             v.y = __builtin_fmaf(a[j].y, rs, -o.y);
@@ -418,7 +433,8 @@ struct R16Row {
         }
 #pragma unroll
         for (int k = 0; k < N2; ++k) {
-            const f2_t o = *reinterpret_cast<const f2_t *>(trow + off2(k, i16));
+            f2_t o = *reinterpret_cast<const f2_t *>(trow + off2(k, i16));
+            if (LS) { o.x -= cb; o.y -= cb; }
             f2_t v;
             v.x = __builtin_fmaf(c[k].x, rs, -o.x);
             v.y = __builtin_fmaf(c[k].y, rs, -o.y);
@@ -593,6 +609,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     }
     const bool own[2] = {lst[0] < L, lst[1] < L};
     const float maskv = col_ok ? 0.f : ninf;
+    const bool smooth = p.ls_b != 0.f;                       // (wave-uniform)
     cell_t *const spare_w = reinterpret_cast<cell_t *>(sm.dummy);
     float rs[G];                                             // grad_scale / sum_c exp(x - max), 0 for dead rows
 #pragma unroll
@@ -608,6 +625,11 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         const bool live = t >= 0 && t < Tb;
         float m = x.max(maskv);
         row16_allmax(m);
+        float sx = 0.f;                                      // label smoothing: sum of the row's logits
+        if (smooth) {
+            sx = x.sum(col_ok);
+            row16_allsum(sx);
+        }
         if (CTC_DIAG(p) < 0 && g == 0) stamp(p, 6);               // diagnostic: the first group's rows are there
         // raw rows -> tile, labels' logits back
         x.to_tile(trow, i16);
@@ -622,9 +644,12 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         const float l2sum = __builtin_amdgcn_logf(sum);
         rs[g] = live ? p.grad_scale * __builtin_amdgcn_rcpf(sum) : 0.f;
         // emissions e = log_softmax(x)[lab_l] in log2 units, split into 2^floor * 2^frac
+        // (smoothed: a lp[c_l] + b sum_n lp[n], sum_n lp[n] = (sum_n x_n - C max) log2e - C log2 sum, NoBlankCTC.py:100-107)
+        const float s2 = smooth ? p.ls_b * __builtin_fmaf(sx - (float)p.C * m, kLog2e, -(float)p.C * l2sum) : 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const float e2 = fmaxf(__builtin_fmaf(xv[s] - m, kLog2e, -l2sum), kXrMinLog2);
+            const float ec = __builtin_fmaf(xv[s] - m, kLog2e, -l2sum);
+            const float e2 = fmaxf(smooth ? __builtin_fmaf(p.ls_a, ec, s2) : ec, kXrMinLog2);
             const float fl = __builtin_floorf(e2);
             const float pm = __builtin_amdgcn_exp2f(e2 - fl);
             cell_t *dst = (live && lst[s] < p.SP) ? sm.em + lst[s] * sm.TP + t : spare_w;
@@ -716,7 +741,8 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         for (int s = 0; s < 2; ++s) z[s] = __builtin_amdgcn_ldexpf(pr[s], ks[s] - km);
         float tot = z[0] + z[1];
         row16_allsum(tot);
-        float rinv = (live && tot > 0.f) ? gsc * __builtin_amdgcn_rcpf(tot) : 0.f;
+        // (smoothed: grad = (1 - b) softmax - a occupancy - b, all times 1/B on live rows)
+        float rinv = (live && tot > 0.f) ? gsc * p.ls_a * __builtin_amdgcn_rcpf(tot) : 0.f;
         if (starved) {                                       // never observed; loud if a hand-off were broken
             rinv = __builtin_nanf("");
             raise_status(p.counter, kStatusNoblankStarved);
@@ -736,7 +762,11 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         }
         lds_order();
         // dense rows: grad = softmax(x) * scale - occupancy   (dead rows: scale = occupancy = 0)
-        if (t >= 0) x.template store_grad<NT>(p.grad + ((int64_t)t * p.B + b) * p.C, trow, i16, rs[g], col_ok);
+        if (t >= 0) {
+            float *gp = p.grad + ((int64_t)t * p.B + b) * p.C;
+            if (smooth) x.template store_grad<NT, true>(gp, trow, i16, rs[g] * (1.f - p.ls_b), col_ok, live ? -p.ls_b * gsc : 0.f);
+            else x.template store_grad<NT, false>(gp, trow, i16, rs[g], col_ok, 0.f);
+        }
         lds_order();
     }
     stamp(p, 7);

@@ -148,7 +148,7 @@ def _variant_of(targets):
                      "%s %s" % (tuple(targets.shape), targets.dtype))
 
 
-def _launch(variant, x, targets, in_len, tgt_len, want_grad, batch_total, blank=0):
+def _launch(variant, x, targets, in_len, tgt_len, want_grad, batch_total, blank=0, label_smoothing=None):
     """Validate, allocate outputs and enqueue the fused kernel.  -> (loss, nll, grad|None)"""
     if x.__class__ is not torch.Tensor and not isinstance(x, torch.Tensor) or not x.is_cuda:
         _require_hip(x, "log_probs")
@@ -195,7 +195,14 @@ def _launch(variant, x, targets, in_len, tgt_len, want_grad, batch_total, blank=
         ws = _workspace(variant, T, B, C, S, dev, stream)
         gp = grad.data_ptr() if want_grad else None
         op = out.data_ptr()
-        if variant == _lib.NOBLANK:
+        if variant == _lib.NOBLANK and label_smoothing is not None:
+            rc = lib.ctc_amd_noblank_smoothed_loss_grad(
+                xs.data_ptr(), st, sb, tg.data_ptr(), int(tg.dtype is torch.int64),
+                il.data_ptr(), tl.data_ptr(), T, B, C, S, float(label_smoothing), scale, scale,
+                op, op + 4 * B, gp, ws.data_ptr(), stream)
+            if rc:
+                _lib.check(rc, "ctc_amd_noblank_smoothed_loss_grad")
+        elif variant == _lib.NOBLANK:
             rc = lib.ctc_amd_noblank_loss_grad(
                 xs.data_ptr(), st, sb, tg.data_ptr(), int(tg.dtype is torch.int64),
                 il.data_ptr(), tl.data_ptr(), T, B, C, S, scale, scale,
@@ -227,8 +234,9 @@ def _scaled_grad(ctx, gout):
     ctx.grad = None                         # the buffer is handed to autograd exactly once
     if grad is None:                        # backward again (retain_graph): recompute
         x, targets = ctx.saved_tensors
-        variant, batch_total, blank = ctx.meta
-        _, _, grad = _launch(variant, x, targets, ctx.lens[0], ctx.lens[1], True, batch_total, blank)
+        variant, batch_total, blank = ctx.meta[:3]
+        smoothing = ctx.meta[3] if len(ctx.meta) > 3 else None
+        _, _, grad = _launch(variant, x, targets, ctx.lens[0], ctx.lens[1], True, batch_total, blank, smoothing)
     g = gout
     if g.dtype is not torch.float32 or g.device != grad.device or not g.is_contiguous() or g.requires_grad:
         g = g.detach().to(device=grad.device, dtype=torch.float32).contiguous()
@@ -244,11 +252,11 @@ class _LossFn(torch.autograd.Function):
     """(loss, nll) with the input gradient produced by the forward launch."""
 
     @staticmethod
-    def forward(ctx, x, targets, in_len, tgt_len, variant, batch_total, blank):
+    def forward(ctx, x, targets, in_len, tgt_len, variant, batch_total, blank, label_smoothing=None):
         want = ctx.needs_input_grad[0]
-        loss, nll, grad = _launch(variant, x, targets, in_len, tgt_len, want, batch_total, blank)
+        loss, nll, grad = _launch(variant, x, targets, in_len, tgt_len, want, batch_total, blank, label_smoothing)
         ctx.grad = grad
-        ctx.meta = (variant, batch_total, blank)
+        ctx.meta = (variant, batch_total, blank, label_smoothing)
         if want:
             ctx.save_for_backward(x, targets)
             ctx.lens = (in_len, tgt_len)
@@ -258,7 +266,7 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout, _gnll):
-        return _scaled_grad(ctx, gout), None, None, None, None, None, None
+        return _scaled_grad(ctx, gout), None, None, None, None, None, None, None
 
 
 class CTCLoss(torch.autograd.Function):
@@ -289,9 +297,13 @@ class CTCLoss(torch.autograd.Function):
         return _scaled_grad(ctx, gout), None, None, None, None
 
 
-def noblank_ctc_loss(logits, targets, input_lengths, target_lengths, batch_total=None):
-    """-> (loss, nll[B]); NoBlankCTC arithmetic."""
-    return _LossFn.apply(logits, targets, input_lengths, target_lengths, _lib.NOBLANK, batch_total, 0)
+def noblank_ctc_loss(logits, targets, input_lengths, target_lengths, batch_total=None, label_smoothing=None):
+    """-> (loss, nll[B]); NoBlankCTC arithmetic.
+
+    ``label_smoothing=lam`` selects the emission variant sketched in comments at NoBlankCTC.py:100-107 (the
+    true class weighted lam, every other class (1 - lam) / C); None = the module as shipped."""
+    return _LossFn.apply(logits, targets, input_lengths, target_lengths, _lib.NOBLANK, batch_total, 0,
+                         label_smoothing)
 
 
 def binary_ctc_loss(logits, targets, input_lengths, target_lengths, batch_total=None):

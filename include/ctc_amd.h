@@ -70,6 +70,21 @@ int ctc_amd_noblank_loss_grad(const float *x, int64_t stride_t, int64_t stride_b
                               float *nll, float *loss, float *grad,
                               void *workspace, void *stream);
 
+/* The label-smoothing variant sketched in comments at NoBlankCTC.py:100-107 ("the true class times lambda,
+ * the others times (1 - lambda) / n_unit") and CrossEntropy.py: the emission of label position l becomes
+ *   e[t,b,l] = lambda * lp[t,b,c_l] + (1 - lambda)/C * sum_{n != c_l} lp[t,b,n],   lp = LogSoftmax(x),
+ * everything else as ctc_amd_noblank_loss_grad; grad = grad_scale * ((1 - b) softmax - a occupancy - b) with
+ * b = (1 - lambda)/C, a = lambda - b.  The reference never runs this code (parity unpinned: checked against
+ * the numpy restatement and finite differences).  Shapes: C even <= 256, S <= 31, T <= 168, 8-byte aligned
+ * rows (the four-rows-per-wave kernel); others return CTC_AMD_ERR_UNSUPPORTED_SHAPE.  lambda in [0, 1]. */
+int ctc_amd_noblank_smoothed_loss_grad(const float *x, int64_t stride_t, int64_t stride_b,
+                                       const void *labels, int labels_i64,
+                                       const int64_t *in_len, const int64_t *tgt_len,
+                                       int T, int B, int C, int S, float label_smoothing,
+                                       float loss_scale, float grad_scale,
+                                       float *nll, float *loss, float *grad,
+                                       void *workspace, void *stream);
+
 /* NoBlankBinaryCTC.forward (NoBlankBinaryCTC.py:139-151) + gradient.  Same as above
  * except   y [B,S,C] fp32 multi-hot / soft targets in [0,1], contiguous;
  * emission = -BCELoss(sigmoid(x[t,b,:]), y[b,l,:]) (:112,:88, logs clamped at -100);

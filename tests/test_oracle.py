@@ -96,3 +96,28 @@ def test_numpy_and_c_agree_on_random_shapes():
         a = ctc_numpy.binary_ctc(x, y, Tb, L, np.float64)
         c = ctc_c.binary_ctc(x, y, Tb, L, np.float64, threads=2)
         assert np.abs(a["nll"] - c["nll"]).max() < 1e-9 and np.abs(a["grad"] - c["grad"]).max() < 1e-12
+
+
+def test_label_smoothing_restatement_gradient():
+    """NoBlankCTC.py:100-107 is a comment in the reference (no behaviour to capture): the restatement's
+    closed-form gradient is checked against central differences, and lambda = 1 must be the plain loss."""
+    rng = np.random.default_rng(3)
+    T, B, C, S = 8, 3, 6, 4
+    x = rng.normal(size=(T, B, C))
+    lab = rng.integers(0, C, (B, S))
+    il, tl = np.array([8, 6, 8]), np.array([4, 2, 3])
+    plain = ctc_numpy.noblank_ctc(x, lab, il, tl, np.float64)
+    one = ctc_numpy.noblank_ctc(x, lab, il, tl, np.float64, label_smoothing=1.0)
+    assert np.allclose(one["nll"], plain["nll"], atol=1e-12) and np.allclose(one["grad"], plain["grad"], atol=1e-12)
+    r = ctc_numpy.noblank_ctc(x, lab, il, tl, np.float64, label_smoothing=0.9)
+    assert (r["nll"] < plain["nll"] + 10).all() and abs(r["loss"] - plain["loss"]) > 1e-3
+    eps, g = 1e-6, np.zeros_like(x)
+    for idx in np.ndindex(*x.shape):
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += eps
+        xm[idx] -= eps
+        g[idx] = (ctc_numpy.noblank_ctc(xp, lab, il, tl, np.float64, want_grad=False, label_smoothing=0.9)["loss"] -
+                  ctc_numpy.noblank_ctc(xm, lab, il, tl, np.float64, want_grad=False, label_smoothing=0.9)["loss"]) / (2 * eps)
+    assert np.abs(g - r["grad"]).max() < 1e-7
+    assert np.abs(r["grad"].sum(axis=2)).max() < 1e-12          # rows still sum to zero
+    assert np.abs(r["grad"][6:, 1]).max() == 0.0                # rows beyond T_b

@@ -711,3 +711,27 @@ def test_blank_persistent_launch_beside_a_busy_stream(dev, monkeypatch):
     assert np.isfinite(r["nll"]).all() and np.isfinite(r["grad"]).all()
     assert (np.abs(r["nll"] - ref["nll"]) <= 1e-5 * np.maximum(1, np.abs(ref["nll"]))).all()
     assert np.abs(r["grad"] - ref["grad"]).max() < 2e-6 * 64.0 / B * max(1.0, T / 300.0)
+
+
+# ------------------------------------------------------------------ label-smoothed emission
+@pytest.mark.parametrize("shape", [(20, 4, 10, 5), (150, 16, 158, 20), (60, 5, 64, 31), (33, 3, 62, 7)])
+@pytest.mark.parametrize("lam", [0.9, 0.5, 1.0])
+def test_noblank_label_smoothing(dev, shape, lam):
+    """NoBlankCTC.py:100-107 (commented sketch; parity unpinned): HIP against the numpy restatement in float64."""
+    import ctc_amd
+    T, B, C, S = shape
+    x, lab, Tb, L = synth_noblank(sum(shape), T, B, C, S, var_T=True)
+    ref = ctc_numpy.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64, label_smoothing=lam)
+    r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev, label_smoothing=lam)
+    assert_close(r, ref, 2e-6 * max(1.0, 256.0 / B))
+    assert np.abs(r["grad"].sum(axis=2)).max() < 1e-6
+    if lam == 1.0:                                           # lambda = 1 is the module as shipped
+        plain = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev)
+        assert np.abs(plain["grad"] - r["grad"]).max() < 1e-9 and np.abs(plain["nll"] - r["nll"]).max() < 1e-4
+
+
+def test_noblank_label_smoothing_unsupported_shapes_raise(dev):
+    import ctc_amd
+    x, lab, Tb, L = synth_noblank(1, 20, 2, 11, 4)           # odd C: not the four-rows-per-wave kernel
+    with pytest.raises(ctc_amd.CtcAmdError):
+        ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), Tb.to(dev), L.to(dev), label_smoothing=0.9)
