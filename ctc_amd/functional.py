@@ -384,3 +384,27 @@ def noblank_posteriors(logits, targets, input_lengths, target_lengths):
             _stream_handle(dev))
     _lib.check(rc, "ctc_amd_noblank_posteriors")
     return gamma, nll
+
+
+def dedup_multihot_targets(rows):
+    """Target construction on the device (datasets/charades_ctc_next_pred.py:653-682).
+
+    ``rows`` [B,S,C] integer multi-hot label rows (one row per annotated time step of a clip) ->
+    ``(targets [B,S,C] int32, lengths [B] int64)``: the distinct non-empty rows in order of first
+    appearance, padded with rows of -1 (the block the reference stores as ``o_only_target`` /
+    ``o_target_length``).  ``targets.clamp(min=0).float()`` is the [B,S,C] float input of NoBlankBinaryCTC."""
+    _require_hip(rows, "rows")
+    if rows.dim() != 3 or rows.dtype.is_floating_point:
+        raise ValueError("ctc_amd: rows must be an integer tensor [B,S,C], got %s %s" % (tuple(rows.shape), rows.dtype))
+    B, S, C = rows.shape
+    if B < 1 or S < 1 or C < 1:
+        raise ValueError("ctc_amd: empty rows %s" % (tuple(rows.shape),))
+    r = rows if rows.dtype is torch.int32 and rows.is_contiguous() else rows.to(torch.int32).contiguous()
+    out = torch.empty_like(r)
+    length = torch.empty(B, dtype=torch.int64, device=r.device)
+    with _on_device(r.device):
+        rc = _lib.load().ctc_amd_dedup_multihot_targets(r.data_ptr(), B, S, C, out.data_ptr(), length.data_ptr(),
+                                                        _stream_handle(r.device))
+    if rc:
+        _lib.check(rc, "ctc_amd_dedup_multihot_targets")
+    return out, length

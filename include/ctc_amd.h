@@ -151,6 +151,13 @@ int ctc_amd_noblank_best_path(const float *x, int64_t stride_t, int64_t stride_b
                               int32_t *path, float *score,
                               void *workspace, void *stream);
 
+/* Target construction: the dedup step of the reference's dataset preparation,
+ * datasets/charades_ctc_next_pred.py:653-682 -- out[b] = the distinct non-empty multi-hot rows of rows[b] in
+ * order of first appearance, remaining rows filled with -1 (:676-678); length[b] = how many.  rows, out:
+ * [B,S,C] int32 (entries 0 / 1); length [B] int64.  Bit-exact integer work; no workspace. */
+int ctc_amd_dedup_multihot_targets(const int32_t *rows, int B, int S, int C, int32_t *out, int64_t *length,
+                                   void *stream);
+
 /* Per-step posteriors of the no-blank lattice: gamma[b,t,l] = P(state l at step
  * t | x, targets) = exp(alpha_t(l) + beta_t(l) + nll), the quantity the loss gradient scatters
  * by class; rows sum to 1 for t < T_b and are 0 beyond T_b / L_b.  Same inputs as

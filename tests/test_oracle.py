@@ -121,3 +121,33 @@ def test_label_smoothing_restatement_gradient():
     assert np.abs(g - r["grad"]).max() < 1e-7
     assert np.abs(r["grad"].sum(axis=2)).max() < 1e-12          # rows still sum to zero
     assert np.abs(r["grad"][6:, 1]).max() == 0.0                # rows beyond T_b
+
+
+def test_dedup_targets_restatement_matches_the_reference_algorithm_in_torch():
+    """charades_ctc_next_pred.py:653-682 re-typed with the reference's own tensor operations (IntTensor codes,
+    `not in`) on shapes where int32 codes cannot overflow (C <= 30): pins the numpy restatement."""
+    import torch
+    rng = np.random.default_rng(5)
+    for S, C in ((6, 5), (12, 9), (20, 30)):
+        rows = (rng.random((4, S, C)) < 0.15).astype(np.int32)
+        rows[0, 3] = rows[0, 1]                               # a repeat that is not adjacent
+        rows[1, 2] = 0                                        # an empty row in the middle
+        rows[2] = rows[2, :1]                                 # one distinct row only
+        rows[3] = 0                                           # nothing at all
+        got, length = ctc_numpy.dedup_multihot_targets(rows)
+        for b in range(4):
+            tgt = torch.tensor(rows[b], dtype=torch.int32)
+            code = torch.IntTensor(S).zero_()
+            for t in range(S):
+                for o in range(C):
+                    code[t] += tgt[t, o] * 2 ** o
+            only, only_code, n = torch.IntTensor(S, C).zero_(), torch.IntTensor(S).zero_(), 0
+            for t in range(S):
+                if code[t] not in only_code:
+                    only_code[t] = code[t]
+                    only[n] = tgt[t]
+                    n += 1
+            for pad in range(S - n):
+                only[n + pad] = -1
+            assert n == int(length[b]) and (only.numpy() == got[b]).all()
+    assert int(length[3]) == 0 and int(length[2]) <= 1

@@ -735,3 +735,26 @@ def test_noblank_label_smoothing_unsupported_shapes_raise(dev):
     x, lab, Tb, L = synth_noblank(1, 20, 2, 11, 4)           # odd C: not the four-rows-per-wave kernel
     with pytest.raises(ctc_amd.CtcAmdError):
         ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), Tb.to(dev), L.to(dev), label_smoothing=0.9)
+
+
+# ------------------------------------------------------------------ target construction
+@pytest.mark.parametrize("shape", [(1, 1, 1), (4, 6, 5), (9, 20, 33), (16, 150, 158), (3, 70, 300), (5, 200, 38)])
+def test_dedup_multihot_targets_bit_exact(dev, shape):
+    """integer work: bit-exact against the numpy restatement of charades_ctc_next_pred.py:653-682"""
+    import ctc_amd
+    B, S, C = shape
+    rng = np.random.default_rng(B * 1000 + S)
+    base = (rng.random((B, max(1, S // 3), C)) < 0.1).astype(np.int32)
+    pick = rng.integers(0, base.shape[1], (B, S))             # many repeats, adjacent and not
+    rows = np.take_along_axis(base, pick[:, :, None].repeat(C, 2), axis=1)
+    rows[0, S // 2] = 0                                       # an empty row
+    if B > 1:
+        rows[1] = 0                                           # a clip without any label
+    ref, ref_len = ctc_numpy.dedup_multihot_targets(rows)
+    out, length = ctc_amd.dedup_multihot_targets(torch.tensor(rows).to(dev))
+    torch.cuda.synchronize()
+    assert (np_(length) == ref_len).all() and (np_(out) == ref).all()
+    # int64 input, same answer; the block feeds the binary loss after the reference's .float()
+    out64, len64 = ctc_amd.dedup_multihot_targets(torch.tensor(rows).long().to(dev))
+    assert (np_(out64) == ref).all() and (np_(len64) == ref_len).all()
+    assert out.dtype == torch.int32 and length.dtype == torch.int64
