@@ -63,6 +63,9 @@ __device__ __forceinline__ void grad_store(V *p, V v)
 constexpr unsigned kStatusNoblankStarved = 1u, kStatusBinaryStarved = 2u, kStatusBlankStarved = 4u;
 __device__ __forceinline__ void raise_status(unsigned *counter, unsigned bit)
 {
+#ifdef CTC_X_NOSTATUS
+    return;
+#endif
     if (lane_id() == 0) __hip_atomic_fetch_or(counter + 2, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
