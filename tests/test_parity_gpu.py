@@ -473,7 +473,11 @@ def test_noblank_extreme_logits_keep_full_range(dev):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 1, 1), (170, 2, 40, 12), (160, 2, 158, 20), (30, 2, 257, 6),
-                                   (30, 3, 64, 64), (20, 2, 30, 70)])
+                                   (30, 3, 64, 64), (20, 2, 30, 70),
+                                   # the pipelined kernel's own edges: T = 168 / 169, fewer than six rounds, odd T,
+                                   # four column chunks with four label tiles, a lone emission tile
+                                   (168, 2, 40, 12), (169, 2, 40, 12), (161, 3, 158, 20), (29, 2, 256, 64),
+                                   (3, 2, 20, 3), (28, 3, 63, 63), (15, 2, 130, 17), (57, 2, 129, 33)])
 def test_binary_kernel_path_boundaries(dev, shape):
     import ctc_amd
     T, B, C, S = shape
@@ -482,6 +486,30 @@ def test_binary_kernel_path_boundaries(dev, shape):
     ref = ctc_c.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float64)
     r = run_hip(ctc_amd.binary_ctc_loss, x, y, Tb, L, dev)
     assert_close(r, ref, 2e-7 * max(1.0, 256.0 / B))
+
+
+def test_binary_rows_with_and_without_tails(dev):
+    """The pipelined kernel takes the cheap form of the logs per ROW (every element in (-16, 6)) and the careful
+    one otherwise: a batch that mixes both kinds of rows, including |x| > 27 (floored BCE denominator), +-inf-ish
+    logits and rows that are entirely in the tail, against the float64 oracle and the float32 port."""
+    import ctc_amd
+    T, B, C, S = 150, 12, 158, 20
+    x, y, Tb, L = synth_binary(5, T, B, C, S, var_T=True, density=0.1)
+    g = torch.Generator().manual_seed(9)
+    rows = torch.rand(T, B, generator=g) < 0.3                     # 30 % of the rows get tails
+    bump = torch.where(torch.rand(T, B, C, generator=g) < 0.05, torch.randn(T, B, C, generator=g) * 12.0,
+                       torch.zeros(T, B, C))
+    x = x + bump * rows[:, :, None]
+    x[7, 0] = x[7, 0] * 10.0                                       # a row that is all tail
+    x[8, 1, :5] = torch.tensor([-16.0, 6.0, -15.999, 5.999, 30.0]) # the edges of the cheap range
+    ref64 = ctc_c.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float64, threads=8)
+    ref32 = ctc_c.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float32, threads=8)
+    r = run_hip(ctc_amd.binary_ctc_loss, x, y, Tb, L, dev)
+    assert np.isfinite(r["grad"]).all()
+    assert (np.abs(r["nll"] - ref32["nll"]) <= 1e-4 * np.abs(ref32["nll"])).all()
+    # (the float32 arithmetic of the reference itself is what limits the agreement with float64 in the tails)
+    err32 = np.abs(ref32["grad"] - ref64["grad"]).max()
+    assert np.abs(r["grad"] - ref64["grad"]).max() <= max(2e-6, 2.0 * err32)
 
 
 def test_unsupported_shapes_raise(dev):
