@@ -67,6 +67,14 @@ constexpr int kLandLag = 16;         // lattice stores that may still be in flig
                                      // measure the same, 48 is 1.5 % slower: the workers hear of rows later)
 constexpr size_t kFusedLdsHead = 64; // bytes of LDS flags in front of the rings
 constexpr int kPastLattice = 1 << 30; // a byte offset beyond any sample's lattice (out-of-range buffer accesses are dropped)
+// Persistent launch: only every other lattice row goes to memory -- alpha on even rows, beta' on odd rows -- and the
+// worker of a row PAIR (2P, 2P+1) redoes one forward and one backward step from the two log_probs rows it holds
+// anyway (0.2 GB less traffic at B=64 T=2000 S=100, and half the chains' stores).
+#ifdef CTC_X_FULL_LATTICE
+constexpr bool kHalfLattice = false;
+#else
+constexpr bool kHalfLattice = true;
+#endif
 
 // ints of hand-off state behind the per-sample tables (see BlankParams::sync)
 int blank_sync_ints(int T, int B)
@@ -563,7 +571,9 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
     // the hardware drops their part of the store (config 5: 13 of 64 lanes, a fifth of the lattice bytes)
     const int lane_off = s0 < n ? s0 * (int)sizeof(float) : kPastLattice;
     auto store = [&](int i, const float (&e)[K]) {
-        const int off = (FWD ? i : Tb - 1 - i) * p.NSP * (int)sizeof(float) + lane_off;
+        const int t = FWD ? i : Tb - 1 - i;
+        if (kHalfLattice && (t & 1) != (FWD ? 0 : 1)) return;   // (wave-uniform) the workers recompute this row
+        const int off = t * p.NSP * (int)sizeof(float) + lane_off;
         if (FWD) {
             agent_store_row<K>(orsrc, off, a);
         } else {
@@ -596,7 +606,8 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
         // Only stores go through this wave's vector-memory counter, it retires in order, and a step
         // issues at least one: at most kLandLag outstanding => the rows of the steps before
         // i + G - kLandLag have landed.
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLandLag) : "memory");
+        // (every other step stores when only half of the lattice is kept: half as many may be outstanding)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kHalfLattice ? kLandLag / 2 : kLandLag) : "memory");
         if (lane == 0 && i + G > kLandLag) agent_store(prog, i + G - kLandLag);
     }
     if (i < Tb) {
@@ -766,6 +777,7 @@ struct BlankTables {
     int b = -1;
     int cls[K], nxt[K];
     bool first[K];
+    bool skipf[K], skipb[K];                                 // (row pairs) the s-2 / s+2 edge of a forward / backward step
 };
 template <int K>
 __device__ __forceinline__ void blank_tables_for(const BlankParams &p, int b, BlankTables<K> &tb, int *nxt_l)
@@ -779,6 +791,12 @@ __device__ __forceinline__ void blank_tables_for(const BlankParams &p, int b, Bl
         tb.nxt[k] = p.nxt[b * p.NSP + s0 + k];
         tb.first[k] = p.first[b * p.NSP + s0 + k] != 0;
         nxt_l[s0 + k] = tb.nxt[k];
+    }
+    if (kHalfLattice) {
+        bool valid[K];
+        const int n = 2 * p.meta[b].y + 1;
+        blank_state_flags<K, true>(p, b, n, tb.skipf, valid);
+        blank_state_flags<K, false>(p, b, n, tb.skipb, valid);
     }
 }
 
@@ -856,6 +874,225 @@ __device__ __forceinline__ void blank_row_finish(const BlankParams &p, const Bla
         const int s = s0 + k;
         if ((s & 1) && s < n) occ[tb.cls[k]] = 0.f;
     }
+}
+
+// ---- row PAIRS (persistent launch with half of the lattice in memory) -----------------------------------
+// A pair is rows t = 2P and t + 1 of a sample.  Memory holds alpha_t and beta'_{t+1}; with e = the emissions of
+// row t + 1 gathered from the log_probs row the wave holds anyway:
+//     alpha_{t+1} = step_fwd(alpha_t) + e          (bit-identical to the chain's own row)
+//     beta'_t     = step_bwd(beta'_{t+1} + e)      (the chain's beta_{t+1} up to one rounding)
+// The last row of a sample with an odd number of rows has no partner: beta' there is the entry condition.
+template <int K>
+struct BlankPair {
+    float4 x0[kMaxV4], x1[kMaxV4];
+    float al[K], be[K];
+    int t, b, Tb, L;                                         // t: the even row, < 0: no pair here
+    bool live0, live1, exist1;                               // rows t / t+1 inside T_b; row t+1 inside T
+    bool poison;
+};
+
+// idx = (2 m + side) B + b over PAIR distances m, the analogue of blank_row_load<SYNC>'s order
+template <int K, bool VEC4>
+__device__ __forceinline__ void blank_pair_load(const BlankParams &p, int idx, BlankPair<K> &r, ChainsSeen &ps)
+{
+    const int lane = lane_id();
+    const int q = idx / p.B;
+    r.b = __builtin_amdgcn_readfirstlane(idx - q * p.B);
+    const int2 meta = p.meta[r.b];
+    const int Te = meta.x;                                   // 0 without an alignment: every row is a zero row
+    r.Tb = Te;
+    r.L = meta.y;
+    r.poison = false;
+    const int Tp = (p.T + 1) >> 1, Tep = (Te + 1) >> 1, m = q >> 1;
+    int P;
+    if ((q & 1) == 0) P = (m < Tp && (m >= Tep || 2 * m >= Tep - 1)) ? m : -1;
+    else P = (m < Tep && Tep - 1 - m < m) ? Tep - 1 - m : -1;
+    P = __builtin_amdgcn_readfirstlane(P);
+    r.t = P < 0 ? -1 : 2 * P;
+    r.live0 = r.t >= 0 && r.t < Te;
+    r.live1 = r.t >= 0 && r.t + 1 < Te;
+    r.exist1 = r.t >= 0 && r.t + 1 < p.T;
+    if (!r.live0) return;                                    // wave-uniform
+    const int lane_off = lane * K < 2 * r.L + 1 ? lane * K * (int)sizeof(float) : kPastLattice;
+    if (!wait_chains(p, r.b, r.t + 1, r.live1 ? Te - (r.t + 1) : 0, ps)) { r.poison = true; return; }
+    agent_load_row<K>(lattice_rsrc(p.al + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), r.t * p.NSP * (int)sizeof(float) + lane_off, r.al);
+    if (r.live1)
+        agent_load_row<K>(lattice_rsrc(p.be + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), (r.t + 1) * p.NSP * (int)sizeof(float) + lane_off, r.be);
+    if (VEC4) {
+        const float *row = p.lp + (int64_t)r.t * p.st + (int64_t)r.b * p.sb;
+#pragma unroll
+        for (int i = 0; i < kMaxV4; ++i) {
+            const int q4 = lane + kWave * i;
+            r.x0[i] = q4 < (p.C >> 2) ? reinterpret_cast<const float4 *>(row)[q4] : make_float4(0, 0, 0, 0);
+        }
+        if (r.live1) {
+#pragma unroll
+            for (int i = 0; i < kMaxV4; ++i) {
+                const int q4 = lane + kWave * i;
+                r.x1[i] = q4 < (p.C >> 2) ? reinterpret_cast<const float4 *>(row + p.st)[q4] : make_float4(0, 0, 0, 0);
+            }
+        }
+    }
+}
+
+// gamma of one row (v: alpha + beta' in log2 units, this lane's K states) -> its gradient row
+template <int K, bool VEC4>
+__device__ __forceinline__ void blank_row_emit(const BlankParams &p, int t, int b, int L, float (&v)[K], const float4 (&xr)[kMaxV4],
+                                               float *occ, float *gam, const int *nxt_l, const BlankTables<K> &tb)
+{
+    const int lane = lane_id(), s0 = lane * K, n = 2 * L + 1;
+    float *g = p.grad + ((int64_t)t * p.B + b) * p.C;
+    float m = kNegB;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = s0 + k < n ? v[k] : kNegB;
+        m = fmaxf(m, v[k]);
+    }
+    m = wave_max(m);
+    float ssum = 0.f, blank_part = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = s0 + k < n ? __builtin_amdgcn_exp2f(v[k] - m) : 0.f;     // lattice is in log2 units
+        ssum += v[k];
+        if (((s0 + k) & 1) == 0) blank_part += v[k];
+    }
+    ssum = wave_sum(ssum);
+    blank_part = wave_sum(blank_part);
+    const float inv = 1.0f / ssum;
+#pragma unroll
+    for (int k = 0; k < K; ++k) gam[s0 + k] = v[k] * inv;            // wave-local LDS, in order
+    if (lane == 0) occ[p.blank] = blank_part * inv;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (tb.first[k]) {                                    // label states only; repeats are chained
+            float tot = gam[s0 + k];
+            for (int q = tb.nxt[k]; q >= 0; q = nxt_l[q]) tot += gam[q];
+            occ[tb.cls[k]] = tot;
+        }
+    }
+    const float gs = p.grad_scale / (float)(L > 1 ? L : 1);
+    if (VEC4) {
+#pragma unroll
+        for (int i = 0; i < kMaxV4; ++i) {
+            const int q = lane + kWave * i;
+            if (q < (p.C >> 2)) {
+                const float4 o = reinterpret_cast<const float4 *>(occ)[q];
+                float4 out;
+                out.x = (fast_exp(xr[i].x) - o.x) * gs;
+                out.y = (fast_exp(xr[i].y) - o.y) * gs;
+                out.z = (fast_exp(xr[i].z) - o.z) * gs;
+                out.w = (fast_exp(xr[i].w) - o.w) * gs;
+                stream_store(reinterpret_cast<float4 *>(g) + q, out);
+            }
+        }
+    } else {
+        const float *row = p.lp + (int64_t)t * p.st + (int64_t)b * p.sb;
+        for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], (fast_exp(row[c]) - occ[c]) * gs);
+    }
+    // un-set only what this row touched
+    if (lane == 0) occ[p.blank] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int s = s0 + k;
+        if ((s & 1) && s < n) occ[tb.cls[k]] = 0.f;
+    }
+}
+
+template <bool VEC4>
+__device__ __forceinline__ void blank_row_fill(const BlankParams &p, int t, int b, float z)
+{
+    const int lane = lane_id();
+    float *g = p.grad + ((int64_t)t * p.B + b) * p.C;
+    if (VEC4) {
+        for (int q = lane; q < (p.C >> 2); q += kWave) stream_store(reinterpret_cast<float4 *>(g) + q, make_float4(z, z, z, z));
+    } else {
+        for (int c = lane; c < p.C; c += kWave) stream_store(&g[c], z);
+    }
+}
+
+template <int K, bool VEC4>
+__device__ __forceinline__ void blank_pair_finish(const BlankParams &p, const BlankPair<K> &r, float *occ, float *gam, float *stage,
+                                                  BlankTables<K> &tb)
+{
+    const int lane = lane_id(), s0 = lane * K;
+    int *nxt_l = reinterpret_cast<int *>(gam + p.NSP);
+    if (r.t < 0) return;                                     // this index names no pair
+    if (!r.live0 || r.poison) {
+        const float z = r.poison ? __builtin_nanf("") : 0.f;
+        blank_row_fill<VEC4>(p, r.t, r.b, z);
+        if (r.exist1) blank_row_fill<VEC4>(p, r.t + 1, r.b, z);
+        return;
+    }
+    const int n = 2 * r.L + 1;
+    blank_tables_for<K>(p, r.b, tb, nxt_l);
+    float a0[K], b0[K];                                      // alpha_t, beta'_t
+#pragma unroll
+    for (int k = 0; k < K; ++k) a0[k] = s0 + k < n ? r.al[k] : kNegB;
+    if (r.live1) {
+        float e1[K];                                         // emissions of row t + 1, log2 units (as the loaders make them)
+        if (VEC4) {
+#pragma unroll
+            for (int i = 0; i < kMaxV4; ++i) reinterpret_cast<float4 *>(stage)[lane + kWave * i] = r.x1[i];
+            asm volatile("" ::: "memory");                   // (same wave: LDS keeps program order)
+#pragma unroll
+            for (int k = 0; k < K; ++k) e1[k] = s0 + k < n ? fmaxf(stage[tb.cls[k]] * kLog2e, kNegB) : kNegB;
+        } else {
+            const float *row1 = p.lp + (int64_t)(r.t + 1) * p.st + (int64_t)r.b * p.sb;
+#pragma unroll
+            for (int k = 0; k < K; ++k) e1[k] = s0 + k < n ? fmaxf(row1[tb.cls[k]] * kLog2e, kNegB) : kNegB;
+        }
+        float a1[K], b1[K], zero[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            a1[k] = a0[k];
+            b1[k] = s0 + k < n ? r.be[k] : kNegB;            // beta'_{t+1}
+            b0[k] = b1[k] + e1[k];                           // beta_{t+1} with its emission
+            zero[k] = 0.f;
+        }
+        blank_step<K, true>(a1, e1, tb.skipf);               // alpha_{t+1}
+        blank_step<K, false>(b0, zero, tb.skipb);            // beta'_t
+        float v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = a0[k] + b0[k];
+        blank_row_emit<K, VEC4>(p, r.t, r.b, r.L, v, r.x0, occ, gam, nxt_l, tb);
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = a1[k] + b1[k];
+        blank_row_emit<K, VEC4>(p, r.t + 1, r.b, r.L, v, r.x1, occ, gam, nxt_l, tb);
+    } else {
+        float v[K];                                          // the sample's last row: beta' is the entry condition
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int s = s0 + k;
+            v[k] = (s == n - 1 || s == n - 2) ? a0[k] : kNegB;
+        }
+        blank_row_emit<K, VEC4>(p, r.t, r.b, r.L, v, r.x0, occ, gam, nxt_l, tb);
+        if (r.exist1) blank_row_fill<VEC4>(p, r.t + 1, r.b, 0.f);
+    }
+}
+
+// wave `first` of `stride` takes pairs first, first+stride, ...; three pairs (six rows) in flight
+template <int K, bool VEC4>
+__device__ __forceinline__ void blank_grad_pairs(const BlankParams &p, int first, int stride, int total, float *occ, float *gam, float *stage)
+{
+    int idx = first;
+    if (idx >= total) return;
+    BlankTables<K> tb;
+    ChainsSeen ps;
+    BlankPair<K> r0, r1, r2;
+    constexpr int NB = 3;
+    blank_pair_load<K, VEC4>(p, idx, r0, ps);
+    if (idx + stride < total) blank_pair_load<K, VEC4>(p, idx + stride, r1, ps);
+#define CTC_TURN(Q, CUR, NEXT)                                                                                 \
+    if (idx + (Q)*stride < total) {                                                                            \
+        if (idx + ((Q) + NB - 1) * stride < total) blank_pair_load<K, VEC4>(p, idx + ((Q) + NB - 1) * stride, NEXT, ps); \
+        blank_pair_finish<K, VEC4>(p, CUR, occ, gam, stage, tb);                                               \
+    }
+    for (; idx < total; idx += NB * stride) {
+        CTC_TURN(0, r0, r2)
+        CTC_TURN(1, r1, r0)
+        CTC_TURN(2, r2, r1)
+    }
+#undef CTC_TURN
 }
 
 // VEC4: C % 4 == 0 and 16-byte aligned rows -> the dense part moves float4 per lane (4x fewer
@@ -956,20 +1193,27 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void blank_fused_kernel(BlankP
         }
         return;
     }
-    const int C4 = (p.C + 3) & ~3;                           // a row worker: per wave occ[C4] + gam[NSP] + nxt[NSP]
-    float *occ = reinterpret_cast<float *>(s_buf4) + (size_t)w * (C4 + 2 * p.NSP);
+    // a row worker: per wave occ[C4] + gam[NSP] + nxt[NSP] (+ a staged log_probs row when it works on row pairs)
+    const int C4 = (p.C + 3) & ~3;
+    const int per_wave = C4 + 2 * p.NSP + (kHalfLattice && VEC4 ? 4 * kWave * kMaxV4 : 0);
+    float *occ = reinterpret_cast<float *>(s_buf4) + (size_t)w * per_wave;
     float *gam = occ + C4;
     for (int c = lane; c < C4; c += kWave) occ[c] = 0.f;
     const int wid = ((int)blockIdx.x - p.B) * kFusedWaves + w, nw = ((int)gridDim.x - p.B) * kFusedWaves;
     if (wid == 0) bstamp(p, 0);
     if (wid == nw - 1) bstamp(p, 15);
     // rows exist from distance (T_b - 1)/2 on (the middle of the sample): start at the smallest one of the batch
+    // (row pairs: the same in units of pairs)
     int m0 = p.T;
-    for (int bb = lane; bb < p.B; bb += kWave) m0 = min(m0, (max(p.meta[bb].x, 1) - 1) >> 1);
+    for (int bb = lane; bb < p.B; bb += kWave) {
+        const int len = kHalfLattice ? (p.meta[bb].x + 1) >> 1 : p.meta[bb].x;
+        m0 = min(m0, (max(len, 1) - 1) >> 1);
+    }
 #pragma unroll
     for (int sh = 1; sh < kWave; sh <<= 1) m0 = min(m0, __shfl_xor(m0, sh));
     m0 = __builtin_amdgcn_readfirstlane(m0);
-    blank_grad_rows<K, VEC4, true>(p, m0 * 2 * p.B + wid, nw, 2 * p.T * p.B, occ, gam);
+    if (kHalfLattice) blank_grad_pairs<K, VEC4>(p, m0 * 2 * p.B + wid, nw, 2 * ((p.T + 1) >> 1) * p.B, occ, gam, gam + 2 * p.NSP);
+    else blank_grad_rows<K, VEC4, true>(p, m0 * 2 * p.B + wid, nw, 2 * p.T * p.B, occ, gam);
     if (wid == 0) bstamp(p, 12);
     if (wid == nw - 1) bstamp(p, 13);
     if (wid == nw / 2) bstamp(p, 14);
@@ -1049,7 +1293,8 @@ static int run_blank(BlankParams &p, hipStream_t s)
         // more than half of a CU's LDS per workgroup: one workgroup per CU, the chains share their SIMDs with nobody
         size_t lds = kFusedLdsHead + 2 * (size_t)(kRingRows / K) * p.NSP * sizeof(float) +
                      (vec4 ? 2 * kLoaders * (size_t)(4 * kWave * kMaxV4) * sizeof(float) : 0);   // + a row per loader
-        if (lds < kFusedWaves * row_lds) lds = kFusedWaves * row_lds;
+        const size_t worker_lds = row_lds + (kHalfLattice && vec4 ? (size_t)4 * kWave * kMaxV4 * sizeof(float) : 0);
+        if (lds < kFusedWaves * worker_lds) lds = kFusedWaves * worker_lds;
         if (lds < kMaxLds / 2 + 1024) lds = kMaxLds / 2 + 1024;
         const int cap = lds <= kMaxLds ? (vec4 ? fused_capacity<K, true>(lds) : fused_capacity<K, false>(lds)) : 0;
         const bool pays = K >= 4 && vec4 && p.T >= 2 * kFusedMinT && 8 * p.B >= cap && 4 * p.B <= cap &&
