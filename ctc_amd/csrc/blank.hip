@@ -59,6 +59,7 @@ constexpr int kAuxAgent = 16;        // buffer-instruction cache policy: sc1 = a
 constexpr int kFusedMinT = 128;      // the persistent launch needs at least this many steps (and pays from twice as many)
 constexpr int kMaxV4 = 4;            // float4 per lane that cover a row of the VEC4 paths (C <= 1024)
 constexpr int kFusedWaves = 8;       // waves of a workgroup of the fused launch
+constexpr int kFusedThreads = kFusedWaves * kWave;
 constexpr int kRingRows = 128;       // x 1/K: emission rows per direction in the LDS ring (32 KB for every K)
 constexpr int kLoadAhead = 12;       // rows each loader wave keeps in flight
 constexpr int kLoaders = 3;          // loader waves per direction (two could not keep up: the chains waited 30 % of the time)
@@ -74,6 +75,24 @@ constexpr int kPastLattice = 1 << 30; // a byte offset beyond any sample's latti
 constexpr bool kHalfLattice = false;
 #else
 constexpr bool kHalfLattice = true;
+#endif
+// Persistent launch, float4 loaders: every log_probs row is gathered ONCE.  The loaders of a direction gather the first
+// half of its steps from log_probs; its CHAIN, which has each emission row in registers anyway, leaves it in the
+// workspace (p.em, the three-launch schedule's emission table; plain stores -- producer and consumer are waves of ONE
+// workgroup, so the CU's L2 is the meeting point); the loaders of the OTHER direction -- for which these rows are the
+// second half -- read the 4 K bytes per lane back instead of whole log_probs rows (0.3 GB less traffic at B=64 T=2000
+// C=1000 S=100, and light loaders while the row workers use the memory system).
+// Tried on the way: a storer wave per direction (ten waves per workgroup leave 168 VGPRs per wave, the loaders' twelve
+// rows in flight spill: 860 us); the loaders storing their own rows (one more line request per row on the busiest
+// unit of the phase: first half 50 instead of 41 us per 256 steps); one loader loop with a branch per row (the
+// compiler must then assume the fewest memory operations behind a row it waits for: three rows in flight, 730 us).
+// MEASURED, NOT ON: 1.94 instead of 2.13 GB and a second half of the chains at 36-46 instead of 44-67 us per 256 steps,
+// but the extra store per step sits on the busiest unit of the first half (the sample's CU issues every log_probs
+// line request of six loaders): the chains cross at 209 instead of 170 us and the launch takes 459 against 447 us.
+#ifdef CTC_X_GATHER_ONCE
+constexpr bool kGatherOnce = true;
+#else
+constexpr bool kGatherOnce = false;
 #endif
 
 // ints of hand-off state behind the per-sample tables (see BlankParams::sync)
@@ -152,33 +171,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lattice_rsrc(const float *base
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, T * NSP * (int)sizeof(float), 0x00020000);
 }
-template <int K>
+template <int K, int AUX = kAuxAgent>
 __device__ __forceinline__ void agent_store_row(__amdgpu_buffer_rsrc_t r, int byte_off, const float (&a)[K])
 {
     if constexpr (K == 2) {
         const i2_t v = {__builtin_bit_cast(int, a[0]), __builtin_bit_cast(int, a[1])};
-        __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, kAuxAgent);
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, AUX);
     } else {
 #pragma unroll
         for (int q = 0; q < K; q += 4) {
             const i4_t v = {__builtin_bit_cast(int, a[q]), __builtin_bit_cast(int, a[q + 1]),
                             __builtin_bit_cast(int, a[q + 2]), __builtin_bit_cast(int, a[q + 3])};
-            __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off + q * 4, 0, kAuxAgent);
+            __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off + q * 4, 0, AUX);
         }
     }
 }
-template <int K>
+template <int K, int AUX = kAuxAgent>
 __device__ __forceinline__ void agent_load_row(__amdgpu_buffer_rsrc_t r, int byte_off, float (&a)[K])
 {
     if constexpr (K == 2) {
-        const i2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, kAuxAgent);
+        const i2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, AUX);
         const int x = v.x, y = v.y;                          // (element reads of a vector go through temporaries)
         a[0] = __builtin_bit_cast(float, x);
         a[1] = __builtin_bit_cast(float, y);
     } else {
 #pragma unroll
         for (int q = 0; q < K; q += 4) {
-            const i4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + q * 4, 0, kAuxAgent);
+            const i4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + q * 4, 0, AUX);
             const int x = v.x, y = v.y, z = v.z, w = v.w;
             a[q] = __builtin_bit_cast(float, x);
             a[q + 1] = __builtin_bit_cast(float, y);
@@ -494,51 +513,92 @@ __device__ __forceinline__ void blank_loader_rows(const BlankParams &p, int b, i
     int *done_flag = f.flags + 4 * dir + j;
     const int *consumed = f.flags + 4 * dir + 3;
     int seen = 0;                                            // steps the chain is known to have consumed
+    // Steps [0, H) of this direction are gathered here (its chain leaves them in the workspace as well); steps >= H are rows
+    // the OTHER direction gathered in its first half: they come back from the workspace, K floats per lane.  Two loops, each
+    // with a FIXED number of memory operations per row in flight: with one loop and a branch per row the compiler must
+    // assume the fewest operations behind a row it waits for, and the twelve rows in flight shrink to three.
+    const int H = kGatherOnce ? (Tb + 1) >> 1 : Tb;
+    const __amdgpu_buffer_rsrc_t ersrc = lattice_rsrc(p.em + (int64_t)b * p.T * p.NSP, p.T, p.NSP);
+    const int lane_off = s0 < n ? s0 * (int)sizeof(float) : kPastLattice;
     auto issue = [&](f4_t (&x)[kMaxV4], int r) {             // row r of the step order (clamped: loaded, not used)
-        const int rr = r < Tb ? r : Tb - 1;
+        const int rr = r < H ? r : H - 1;
         const f4_t *row = reinterpret_cast<const f4_t *>(base + (int64_t)(dir == 0 ? rr : Tb - 1 - rr) * p.st);
 #pragma unroll
         for (int q = 0; q < kMaxV4; ++q) x[q] = row[min(lane + kWave * q, c4 - 1)];   // (past the row: its last float4 again)
     };
-    auto finish = [&](const f4_t (&x)[kMaxV4], int rr, int &done) {   // false: the wait ran out
-#pragma unroll
-        for (int v = 0; v < kMaxV4; ++v) reinterpret_cast<f4_t *>(stage)[lane + kWave * v] = x[v];   // (stage holds 4 x 64 float4)
-        asm volatile("" ::: "memory");                       // (same wave: LDS keeps program order)
-        float e[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) e[k] = s0 + k < n ? fmaxf(stage[c[k]] * kLog2e, kNegB) : kNegB;
+    auto put = [&](const float (&e)[K], int rr, int &done) { // false: the wait ran out
         if (rr - R + 1 > seen && !lds_wait_ge(p, consumed, rr - R + 1, seen)) return false;   // slot still being read
         lds_put<K>(ring + (rr & (R - 1)) * p.NSP, e);
         ++done;                                              // (LDS keeps a wave's program order: row, then count)
         if (lane == 0) wg_store(done_flag, done);
         return true;
     };
+    auto finish = [&](const f4_t (&x)[kMaxV4], int rr, int &done) {
+#pragma unroll
+        for (int v = 0; v < kMaxV4; ++v) reinterpret_cast<f4_t *>(stage)[lane + kWave * v] = x[v];   // (stage holds 4 x 64 float4)
+        asm volatile("" ::: "memory");                       // (same wave: LDS keeps program order)
+        float e[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) e[k] = s0 + k < n ? fmaxf(stage[c[k]] * kLog2e, kNegB) : kNegB;
+        return put(e, rr, done);
+    };
     // kLoadAhead rows in flight, each in its own small array: one big array would stay in scratch
     // memory (the backend only keeps arrays up to a quarter of the register budget in registers)
     static_assert(P == 12, "one named buffer per row in flight");
-    f4_t x0[kMaxV4], x1[kMaxV4], x2[kMaxV4], x3[kMaxV4], x4[kMaxV4], x5[kMaxV4], x6[kMaxV4], x7[kMaxV4], x8[kMaxV4],
-        x9[kMaxV4], x10[kMaxV4], x11[kMaxV4];
+    int done = 0;
+    if (j < H) {
+        f4_t x0[kMaxV4], x1[kMaxV4], x2[kMaxV4], x3[kMaxV4], x4[kMaxV4], x5[kMaxV4], x6[kMaxV4], x7[kMaxV4], x8[kMaxV4],
+            x9[kMaxV4], x10[kMaxV4], x11[kMaxV4];
 #define CTC_EACH_ROW(F) F(0, x0) F(1, x1) F(2, x2) F(3, x3) F(4, x4) F(5, x5) F(6, x6) F(7, x7) F(8, x8) F(9, x9) F(10, x10) F(11, x11)
 #define CTC_FIRST(Q, X) issue(X, j + kLoaders * (Q));
 #define CTC_TURN(Q, X)                                        \
     {                                                         \
         const int rr = r + kLoaders * (Q);                    \
-        if (rr < Tb && !finish(X, rr, done)) return;          \
+        if (rr < H && !finish(X, rr, done)) return;           \
         issue(X, rr + kLoaders * P);                          \
     }
-    CTC_EACH_ROW(CTC_FIRST)
-    int done = 0;
-    for (int r = j; r < Tb; r += kLoaders * P) { CTC_EACH_ROW(CTC_TURN) }
+        CTC_EACH_ROW(CTC_FIRST)
+        for (int r = j; r < H; r += kLoaders * P) { CTC_EACH_ROW(CTC_TURN) }
 #undef CTC_TURN
 #undef CTC_FIRST
 #undef CTC_EACH_ROW
+    }
+    if (!kGatherOnce) return;
+    const int r0 = H + (j + kLoaders - H % kLoaders) % kLoaders;   // this loader's first row >= H (rows r = j mod kLoaders)
+    if (r0 >= Tb) return;
+    {
+        // Row r of our step order is the other direction's step Tb-1-r; its CHAIN stored the emission row and publishes
+        // how many of its steps have landed.  Later rows need fewer of them: one wait, for our first row.
+        int seen_landed = 0;
+        if (!lds_wait_ge(p, f.flags + 10 + (1 - dir), Tb - r0, seen_landed)) return;
+    }
+    auto fetch = [&](float (&y)[K], int r) {                 // sc0: past the L1 -- the CU's L2 has the row (same workgroup wrote it)
+        const int rr = r < Tb ? r : Tb - 1;
+        agent_load_row<K, 1>(ersrc, (dir == 0 ? rr : Tb - 1 - rr) * p.NSP * (int)sizeof(float) + lane_off, y);
+    };
+    float y[P][K];
+#pragma unroll
+    for (int q = 0; q < P; ++q) fetch(y[q], r0 + kLoaders * q);
+    for (int r = r0; r < Tb; r += kLoaders * P) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int rr = r + kLoaders * q;
+            if (rr < Tb) {                                   // wave-uniform
+                float e[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) e[k] = s0 + k < n ? y[q][k] : kNegB;   // (lanes past the states read 0)
+                if (!put(e, rr, done)) return;
+            }
+            fetch(y[q], rr + kLoaders * P);
+        }
+    }
 }
 
 // One chain of the fused schedule: emissions from the LDS ring, kGroup steps per hand-off check;
 // lattice rows written through to memory (beta WITHOUT its own emission), and the number of steps
 // whose rows have landed published per group.
 template <int K, bool FWD>
-__device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, int Tb, int L, float (&a)[K], const FusedLds &f)
+__device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, int Tb, int L, float (&a)[K], const FusedLds &f, bool once)
 {
     constexpr int R = kRingRows / K, G = kGroup < R / 2 ? kGroup : R / 2;
     static_assert(G <= R / 2, "a group must fit in the ring twice");
@@ -570,8 +630,13 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
     // lanes whose K states all lie beyond the sample's n states get an offset past the end of the buffer:
     // the hardware drops their part of the store (config 5: 13 of 64 lanes, a fifth of the lattice bytes)
     const int lane_off = s0 < n ? s0 * (int)sizeof(float) : kPastLattice;
+    // gather-once: the emission rows of the first-half steps go to the workspace for the other direction's second half
+    const int H = once ? (Tb + 1) >> 1 : 0;
+    const __amdgpu_buffer_rsrc_t ersrc = lattice_rsrc(p.em + (int64_t)b * p.T * p.NSP, p.T, p.NSP);
+    int *landed = f.flags + 10 + dir;
     auto store = [&](int i, const float (&e)[K]) {
         const int t = FWD ? i : Tb - 1 - i;
+        if (i < H) agent_store_row<K, 0>(ersrc, t * p.NSP * (int)sizeof(float) + lane_off, e);   // (wave-uniform)
         if (kHalfLattice && (t & 1) != (FWD ? 0 : 1)) return;   // (wave-uniform) the workers recompute this row
         const int off = t * p.NSP * (int)sizeof(float) + lane_off;
         if (FWD) {
@@ -590,33 +655,53 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
         blank_first<K, FWD>(a, e0, n);
         store(0, e0);
     }
+    // Two segments when the emission rows are shared (gather-once): steps [1, H) need only this direction's own
+    // loaders; before the first step >= H everything stored so far is drained and published -- the other direction's
+    // second half waits for exactly these rows, and with the usual lag both chains would wait for each other at H.
     int i = 1;
-    for (; i + G <= Tb; i += G) {
-        if (FWD && b == 0 && (i - 1) % 256 == 0) bstamp(p, 1 + (i - 1) / 256);
-        need_rows(i + G - 1);
-        float e[G][K];
+#pragma nounroll
+    for (int seg = 0; seg < 2; ++seg) {
+        const int hi = (seg == 0 && H > 0) ? (H < Tb ? H : Tb) : Tb;
+        for (; i + G <= hi; i += G) {
+            if (FWD && b == 0 && (i - 1) % 256 < G) bstamp(p, 1 + (i - 1) / 256);
+            need_rows(i + G - 1);
+            float e[G][K];
 #pragma unroll
-        for (int j = 0; j < G; ++j) em_row(e[j], i + j);
+            for (int j = 0; j < G; ++j) em_row(e[j], i + j);
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            blank_step<K, FWD>(a, e[j], skip);
-            store(i + j, e[j]);
+            for (int j = 0; j < G; ++j) {
+                blank_step<K, FWD>(a, e[j], skip);
+                store(i + j, e[j]);
+            }
+            if (lane == 0) wg_store(consumed, i + G);        // the loaders may refill these slots
+            // Only stores go through this wave's vector-memory counter, it retires in order, and a step
+            // issues at least one: at most kLandLag outstanding => the rows of the steps before
+            // i + G - kLandLag have landed.
+            // (every other step stores when only half of the lattice is kept: half as many may be outstanding; groups that
+            // also store their emission rows have kLandLag more in the last kLandLag steps)
+            if (i + G <= H) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kHalfLattice ? kLandLag / 2 : kLandLag) + kLandLag) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kHalfLattice ? kLandLag / 2 : kLandLag) : "memory");
+            if (lane == 0 && i + G > kLandLag) {
+                agent_store(prog, i + G - kLandLag);
+                if (once) wg_store(landed, i + G - kLandLag);
+            }
         }
-        if (lane == 0) wg_store(consumed, i + G);            // the loaders may refill these slots
-        // Only stores go through this wave's vector-memory counter, it retires in order, and a step
-        // issues at least one: at most kLandLag outstanding => the rows of the steps before
-        // i + G - kLandLag have landed.
-        // (every other step stores when only half of the lattice is kept: half as many may be outstanding)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kHalfLattice ? kLandLag / 2 : kLandLag) : "memory");
-        if (lane == 0 && i + G > kLandLag) agent_store(prog, i + G - kLandLag);
-    }
-    if (i < Tb) {
-        need_rows(Tb - 1);
-        for (; i < Tb; ++i) {
-            float e[K];
-            em_row(e, i);
-            blank_step<K, FWD>(a, e, skip);
-            store(i, e);
+        if (i < hi) {
+            need_rows(hi - 1);
+            for (; i < hi; ++i) {
+                float e[K];
+                em_row(e, i);
+                blank_step<K, FWD>(a, e, skip);
+                store(i, e);
+            }
+            if (lane == 0 && hi < Tb) wg_store(consumed, i);
+        }
+        if (seg == 0 && H > 0 && hi < Tb) {                  // the end of the first half: drain, publish
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                agent_store(prog, hi);
+                wg_store(landed, hi);
+            }
         }
     }
     if (lane == 0) wg_store(consumed, Tb + R);               // (nothing left to protect)
@@ -627,6 +712,7 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
         reinterpret_cast<unsigned long long *>(p.counter)[8 + 17] = polls;
     }
     if (lane == 0) agent_store(prog, starved ? -1 : Tb);     // (a starved chain never releases its rows)
+    if (lane == 0 && once && !starved) wg_store(landed, Tb);
     if (starved) a[0] = __builtin_nanf("");
 }
 
@@ -1158,7 +1244,7 @@ __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankPar
 
 // ---- fused schedule: the launch -----------------------------------------------------------------
 template <int K, bool VEC4>
-__global__ __launch_bounds__(kFusedWaves * kWave) void blank_fused_kernel(BlankParams p)
+__global__ __launch_bounds__(kFusedThreads) void blank_fused_kernel(BlankParams p)
 {
     extern __shared__ float4 s_buf4[];
     const int w = wave_id(), lane = lane_id();
@@ -1177,10 +1263,10 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void blank_fused_kernel(BlankP
         if (role == 0) {
             __builtin_amdgcn_s_setprio(3);
             if (dir == 0) {
-                if (run) blank_chain_fused<K, true>(p, b, Tb, L, a, f);
+                if (run) blank_chain_fused<K, true>(p, b, Tb, L, a, f, VEC4 && kGatherOnce);
                 blank_publish<K>(p, b, ok, Tb, L, a);
             } else if (run) {
-                blank_chain_fused<K, false>(p, b, Tb, L, a, f);
+                blank_chain_fused<K, false>(p, b, Tb, L, a, f, VEC4 && kGatherOnce);
             }
         } else if (run) {
             const int j = role - 1;
@@ -1235,7 +1321,7 @@ static int fused_capacity(size_t lds)
     int per_cu = 0;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(blank_fused_kernel<K, VEC4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blank_fused_kernel<K, VEC4>, kFusedWaves * kWave, lds) != hipSuccess)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blank_fused_kernel<K, VEC4>, kFusedThreads, lds) != hipSuccess)
         per_cu = 0;
     const int cap = per_cu >= 1 ? device_cus() : 0;
     if (dev >= 0) cache[dev].store(key | (unsigned long long)(cap + 1), std::memory_order_release);
@@ -1302,7 +1388,7 @@ static int run_blank(BlankParams &p, hipStream_t s)
         if (cap >= 2 * p.B && cap - p.B >= 32 && (pays || forced)) {
             int rc = launch<blank_tables_kernel>(dim3(p.B), dim3(256), p.NSP * sizeof(int), s, p);
             if (rc) return rc;
-            const dim3 grid(cap), block(kFusedWaves * kWave);
+            const dim3 grid(cap), block(kFusedThreads);
             if (vec4) return launch<blank_fused_kernel<K, true>>(grid, block, lds, s, p);
             return launch<blank_fused_kernel<K, false>>(grid, block, lds, s, p);
         }
