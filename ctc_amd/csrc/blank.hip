@@ -86,6 +86,11 @@ constexpr bool kHalfLattice = true;
 // rows in flight spill: 860 us); the loaders storing their own rows (one more line request per row on the busiest
 // unit of the phase: first half 50 instead of 41 us per 256 steps); one loader loop with a branch per row (the
 // compiler must then assume the fewest memory operations behind a row it waits for: three rows in flight, 730 us).
+// (Also measured and removed again: the chains of this launch on (mantissa, exponent) states as in noblank_r16.hpp --
+// 52 plain VALU operations per step at four states per lane instead of twelve transcendentals + 40, the loaders
+// splitting each emission into (2^frac, floor), lattice rows still stored as log2 values: correct, and 463 against
+// 430 us on the same device.  The chain's own time per step did not move (0.155 us: it is not bound by its arithmetic
+// but by the per-group hand-offs and the landing window of its stores) and it waited longer for its loaders.)
 // MEASURED, NOT ON: 1.94 instead of 2.13 GB and a second half of the chains at 36-46 instead of 44-67 us per 256 steps,
 // but the extra store per step sits on the busiest unit of the first half (the sample's CU issues every log_probs
 // line request of six loaders): the chains cross at 209 instead of 170 us and the launch takes 459 against 447 us.

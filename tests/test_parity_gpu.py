@@ -333,7 +333,8 @@ def test_blank_nonzero_blank_index_and_wide_rows(dev, shape, monkeypatch):  # to
     assert (np.abs(np_(got_nll)[fin] - np_(nll)[fin]) <= 1e-5 * np.maximum(1, np.abs(np_(nll)[fin]))).all()
     assert np.abs(np_(x.grad)[:, fin] - np_(lpc.grad)[:, fin]).max() < 2e-6 * 64.0 / B
     m = ctc_amd.BlankCTC(blank=blank)
-    assert abs(float(m(lp.to(dev), tgt.to(dev), Tb, L)) - float(got)) < 1e-6
+    # (a forward-only call takes the three launches and their log2-domain chains: the same number to fp32 rounding)
+    assert abs(float(m(lp.to(dev), tgt.to(dev), Tb, L)) - float(got)) <= 2e-6 * max(1.0, abs(float(got)))
 
 
 def test_blank_persistent_launch_is_the_default_for_config5_like_batches(dev, monkeypatch):
