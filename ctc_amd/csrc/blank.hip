@@ -65,7 +65,8 @@ constexpr int kLoadAhead = 12;       // rows each loader wave keeps in flight
 constexpr int kLoaders = 3;          // loader waves per direction (two could not keep up: the chains waited 30 % of the time)
 constexpr int kGroup = 16;           // chain steps between hand-off checks (capped at half a ring; 8: +2 %, 4: +6 %)
 constexpr int kLandLag = 16;         // lattice stores that may still be in flight when progress is published (0..24
-                                     // measure the same, 48 is 1.5 % slower: the workers hear of rows later)
+                                     // measure the same, 48 is 1.5 % slower: the workers hear of rows later; with
+                                     // half of the lattice in memory 16 steps = 8 stores: 32 steps is 0.8 % slower)
 constexpr size_t kFusedLdsHead = 64; // bytes of LDS flags in front of the rings
 constexpr int kPastLattice = 1 << 30; // a byte offset beyond any sample's lattice (out-of-range buffer accesses are dropped)
 // Persistent launch: only every other lattice row goes to memory -- alpha on even rows, beta' on odd rows -- and the
@@ -619,12 +620,21 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
     int have[kLoaders] = {};
     unsigned long long waited = 0, polls = 0;                // (diagnostics)
     auto need_rows = [&](int last) {
+        int need[kLoaders];
+        bool all = true;
 #pragma unroll
         for (int j = 0; j < kLoaders; ++j) {
-            const int need = last >= j ? (last - j) / kLoaders + 1 : 0;
-            if (need > have[j]) {
+            need[j] = last >= j ? (last - j) / kLoaders + 1 : 0;
+            all = all && need[j] <= have[j];
+        }
+        if (all) return;
+#pragma unroll
+        for (int j = 0; j < kLoaders; ++j) have[j] = wg_load(loaded + j);   // (one LDS round trip for the three flags)
+#pragma unroll
+        for (int j = 0; j < kLoaders; ++j) {
+            if (need[j] > have[j]) {
                 const unsigned long long t0 = (p.debug & 128) ? __builtin_amdgcn_s_memtime() : 0;
-                if (!lds_wait_ge(p, loaded + j, need, have[j])) starved = true;
+                if (!lds_wait_ge(p, loaded + j, need[j], have[j])) starved = true;
                 if (p.debug & 128) { waited += __builtin_amdgcn_s_memtime() - t0; ++polls; }
             }
         }
