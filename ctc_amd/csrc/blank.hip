@@ -292,14 +292,6 @@ __global__ __launch_bounds__(256) void blank_tables_kernel(BlankParams p)
 // The blank lattice (em, alpha, beta) is kept in LOG2 units: v_exp_f32 / v_log_f32 are base-2,
 // so a state update is max, subtract, exp2, add, log2, add with no base-conversion multiplies.
 // Only differences alpha+beta-em and the final likelihood (x ln 2) leave the lattice.
-__device__ __forceinline__ float lse3_2(float a, float b, float c)
-{
-    // the largest term is 2^0: sort (v_max3 / v_med3 / v_min3) and take two exponentials instead of three -- a chain
-    // step at four states per lane is ten transcendentals instead of twelve, and they are half of its issue time
-    const float hi = fmaxf(fmaxf(a, b), c), lo = fminf(fminf(a, b), c), mid = __builtin_amdgcn_fmed3f(a, b, c);
-    const float s = 1.0f + __builtin_amdgcn_exp2f(mid - hi) + __builtin_amdgcn_exp2f(lo - hi);
-    return hi + __builtin_amdgcn_logf(s);
-}
 __device__ __forceinline__ float lse2_2(float a, float b)
 {
     const float m = fmaxf(a, b);
@@ -323,30 +315,35 @@ __device__ __forceinline__ void blank_state_flags(const BlankParams &p, int b, i
 }
 
 // one time step of a chain: a <- LSE of the predecessors + e
+// A label state's three predecessors are itself and the two predecessors of the BLANK state next to it (alpha: s-1
+// and s-2 are what blank s-1 comes from; beta: s+1 and s+2, blank s+1), so its sum is 2^a + 2^(that blank's
+// pre-emission value): every state is a two-term log-sum-exp, 8 transcendentals per step at four states per lane
+// instead of 12 (they are half of the step's issue time).  Where the s-2 edge does not exist (repeated label) the
+// second term is the neighbour itself.  Costs one more fp32 rounding on that path (the blank's value is rounded before
+// it is reused); the workers' recomputed rows go through this same function, so they still match the chains' bit for bit.
 template <int K, bool FWD>
 __device__ __forceinline__ void blank_step(float (&a)[K], const float (&e)[K], const bool (&skip)[K])
 {
-    // neighbour lane's two edge states (alpha: previous lane's last two, beta: next lane's first two)
-    const float n1 = FWD ? wave_shr1(a[K - 1], kNegB) : wave_shl1(a[0], kNegB);
-    const float n2 = FWD ? wave_shr1(a[K - 2], kNegB) : wave_shl1(a[1], kNegB);
-    float nx[K];
+    static_assert(K % 2 == 0, "s = lane*K + k: k even <=> blank state");
+    float pre[K];
+    // blank states first (k even): two predecessors, no skip.  States beyond n carry the sentinel emission and just
+    // sink (stay finite: they lose 1e30 per step, fp32 holds that for any T); no per-state masking or clamping.
+    if (FWD) {
+        const float n1 = wave_shr1(a[K - 1], kNegB);          // previous lane's last (label) state
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        float x1, x2;
-        if (FWD) {
-            x1 = k >= 1 ? a[k - 1] : n1;
-            x2 = k >= 2 ? a[k - 2] : (k == 1 ? n1 : n2);
-        } else {
-            x1 = k + 1 < K ? a[k + 1] : n1;
-            x2 = k + 2 < K ? a[k + 2] : (k + 1 < K ? n1 : n2);
-        }
-        // s = lane*K + k with K even: k even <=> blank state (two predecessors, no skip).
-        // States beyond n carry the sentinel emission and just sink (stay finite: they lose
-        // 1e30 per step, fp32 holds that for any T); no per-state masking or clamping.
-        nx[k] = ((k & 1) ? lse3_2(a[k], x1, skip[k] ? x2 : kNegB) : lse2_2(a[k], x1)) + e[k];
+        for (int k = 0; k < K; k += 2) pre[k] = lse2_2(a[k], k >= 1 ? a[k - 1] : n1);
+#pragma unroll
+        for (int k = 1; k < K; k += 2) pre[k] = lse2_2(a[k], skip[k] ? pre[k - 1] : a[k - 1]);
+    } else {
+        const float n1 = wave_shl1(a[0], kNegB);              // next lane's first (blank) state
+#pragma unroll
+        for (int k = 0; k < K; k += 2) pre[k] = lse2_2(a[k], a[k + 1]);
+        const float nb = wave_shl1(pre[0], kNegB);            // ... and what that blank comes from
+#pragma unroll
+        for (int k = 1; k < K; k += 2) pre[k] = lse2_2(a[k], skip[k] ? (k + 1 < K ? pre[k + 1] : nb) : (k + 1 < K ? a[k + 1] : n1));
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) a[k] = nx[k];
+    for (int k = 0; k < K; ++k) a[k] = pre[k] + e[k];
 }
 
 // the first row: the two entry states only
