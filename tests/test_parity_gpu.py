@@ -312,6 +312,34 @@ def test_blank_fused_schedule_edge_cases(dev, schedule, monkeypatch):
     assert np.abs(np_(xv.grad)[:, fin] - ref["grad"][:, fin]).max() < 2e-6 * 64.0 / B
 
 
+@pytest.mark.parametrize("T", [129, 160, 257])
+def test_blank_persistent_launch_row_pairs(dev, T, monkeypatch):
+    """The persistent launch keeps every other lattice row and its workers take rows in pairs (2P, 2P+1): odd and even T,
+    odd and even T_b (an odd T_b leaves its last row without a partner), T_b = 1, 2, 3, T-1, T, lengths that put the
+    chains' crossing on either parity, two / four / eight states per lane -- both schedules against the float64 oracle
+    and against each other."""
+    import ctc_amd
+    for S, C in ((20, 36), (100, 512), (200, 64)):
+        B = 10
+        lp, tgt, Tb, L = synth_blank(5 * T + S, T, B, C, S, var_T=True)
+        Tb[:8] = torch.tensor([1, 2, 3, T - 1, T, T // 2, T // 2 + 1, 7])
+        L[:8] = torch.tensor([1, 1, 2, min(S, (T - 1) // 2), min(S, T // 2), min(S, T // 4), 3, 3])
+        ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64, threads=8)
+        fin = np.isfinite(ref["nll"])
+        assert fin[:8].all()
+        got = {}
+        for schedule in (1, 0):
+            _schedule(monkeypatch, schedule)
+            r = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
+            assert (np.isinf(r["nll"]) == ~fin).all()
+            assert np.abs(r["nll"][fin] - ref["nll"][fin]).max() <= 1e-5 * max(1.0, np.abs(ref["nll"][fin]).max())
+            assert np.abs(r["grad"][:, fin] - ref["grad"][:, fin]).max() < 2e-6 * 64.0 / B
+            for b in range(B):                                 # rows beyond T_b: exactly zero
+                assert np.abs(r["grad"][int(Tb[b]):, b]).max(initial=0.0) == 0.0
+            got[schedule] = r
+        assert np.abs(got[1]["grad"] - got[0]["grad"]).max() < 2e-6 * 64.0 / B
+
+
 @pytest.mark.parametrize("shape", [(40, 3, 12, 6), (150, 3, 1300, 12)])   # three launches; persistent launch with rows
 def test_blank_nonzero_blank_index_and_wide_rows(dev, shape, monkeypatch):  # too wide for the float4 path (C > 1024)
     """blank = C-1 instead of 0 (torch CPU as the comparator), targets drawn from the other classes"""
