@@ -93,7 +93,7 @@ __device__ __forceinline__ void bce_logs_fast(float x, float &p, float &lp, floa
 // thirty (the selects, the exact exponential and the second logarithm of bce_logs_fast exist for the tails):
 //     e = exp(-x), p = 1/(1 + e), log p = -log(1 + e), log(1 - p) = log p - x.
 // log(1 - p) is exact here where the reference rounds 1 - fl(p) first: they differ by <= 2.4e-5 at |x| = 6,
-// 1e-6 of an emission after the mean over C -- the float64 oracle is the closer one of the two.
+// 1e-6 of an emission after the mean over C -- the exact (float64) value is the closer one of the two.
 // gradient store: write-through while logits + gradient fit the memory-side cache, non-temporal beyond (common.hpp)
 template <bool WT>
 __device__ __forceinline__ void bin_store(float *p, float v)
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_pipe_kernel(BinaryParams p
     //     Q = sum_c log(1 - p_c) = -ln2 * log2(prod_j s_j) - sum_j x_j  per lane (the product of <= 4 values
     //     below 9e6 cannot overflow), one exponential per element and one logarithm per lane; the reciprocal
     //     waits until the gradient.  log(1 - p) is exact here where the reference rounds 1 - fl(p) first (they
-    //     differ by <= 2.4e-5 at x = 6: 1e-6 of an emission after the mean over C -- the float64 oracle is the
+    //     differ by <= 2.4e-5 at x = 6: 1e-6 of an emission after the mean over C -- the exact (float64) value is the
     //     closer one); for x < 0 the cancellation in -log s - x costs <= 2e-6 absolute per element.
     // Otherwise: bce_logs_fast per element (the reference's clamps and its rounding of 1 - p).
     unsigned slow = 0;                                       // bit 2g+side: that row took the careful path
