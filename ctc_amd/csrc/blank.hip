@@ -998,7 +998,15 @@ __device__ __forceinline__ void blank_pair_load(const BlankParams &p, int idx, B
     const int lane = lane_id();
     const int q = idx / p.B;
     r.b = __builtin_amdgcn_readfirstlane(idx - q * p.B);
-    const int2 meta = p.meta[r.b];
+    // (through the scalar cache: as a vector load the compiler follows it with s_waitcnt vmcnt(0) -- the value is needed at
+    // once -- and that drains every row load this wave has in flight, once per pair)
+    int2 meta;
+    {
+        unsigned long long bits;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bits) : "s"(p.meta + r.b) : "memory");
+        meta.x = (int)(unsigned)bits;
+        meta.y = (int)(bits >> 32);
+    }
     const int Te = meta.x;                                   // 0 without an alignment: every row is a zero row
     r.Tb = Te;
     r.L = meta.y;
@@ -1012,26 +1020,23 @@ __device__ __forceinline__ void blank_pair_load(const BlankParams &p, int idx, B
     r.live0 = r.t >= 0 && r.t < Te;
     r.live1 = r.t >= 0 && r.t + 1 < Te;
     r.exist1 = r.t >= 0 && r.t + 1 < p.T;
-    if (!r.live0) return;                                    // wave-uniform
+    // The SAME ten loads on every path (dead pairs and missing partners load clamped rows and ignore them): three pairs
+    // are in flight per wave, and the compiler turns "wait for pair P" into "at most <loads issued after P's> still
+    // outstanding" -- with an early exit or a conditional load on any path that number is zero, every pair waited for
+    // ALL loads in flight including the pair just issued, and a wave had one pair's worth of bytes in the air.
+    const int te = r.live0 ? r.t : 0, t1 = r.live1 ? r.t + 1 : te;
     const int lane_off = lane * K < 2 * r.L + 1 ? lane * K * (int)sizeof(float) : kPastLattice;
-    if (!wait_chains(p, r.b, r.t + 1, r.live1 ? Te - (r.t + 1) : 0, ps)) { r.poison = true; return; }
-    agent_load_row<K>(lattice_rsrc(p.al + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), r.t * p.NSP * (int)sizeof(float) + lane_off, r.al);
-    if (r.live1)
-        agent_load_row<K>(lattice_rsrc(p.be + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), (r.t + 1) * p.NSP * (int)sizeof(float) + lane_off, r.be);
+    if (r.live0 && !wait_chains(p, r.b, r.t + 1, r.live1 ? Te - (r.t + 1) : 0, ps)) r.poison = true;
+    agent_load_row<K>(lattice_rsrc(p.al + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), te * p.NSP * (int)sizeof(float) + lane_off, r.al);
+    agent_load_row<K>(lattice_rsrc(p.be + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), t1 * p.NSP * (int)sizeof(float) + lane_off, r.be);
     if (VEC4) {
-        const float *row = p.lp + (int64_t)r.t * p.st + (int64_t)r.b * p.sb;
+        const float4 *row0 = reinterpret_cast<const float4 *>(p.lp + (int64_t)te * p.st + (int64_t)r.b * p.sb);
+        const float4 *row1 = reinterpret_cast<const float4 *>(p.lp + (int64_t)t1 * p.st + (int64_t)r.b * p.sb);
+        const int c4 = p.C >> 2;
 #pragma unroll
-        for (int i = 0; i < kMaxV4; ++i) {
-            const int q4 = lane + kWave * i;
-            r.x0[i] = q4 < (p.C >> 2) ? reinterpret_cast<const float4 *>(row)[q4] : make_float4(0, 0, 0, 0);
-        }
-        if (r.live1) {
+        for (int i = 0; i < kMaxV4; ++i) r.x0[i] = row0[min(lane + kWave * i, c4 - 1)];   // (past the row: its last float4 again)
 #pragma unroll
-            for (int i = 0; i < kMaxV4; ++i) {
-                const int q4 = lane + kWave * i;
-                r.x1[i] = q4 < (p.C >> 2) ? reinterpret_cast<const float4 *>(row + p.st)[q4] : make_float4(0, 0, 0, 0);
-            }
-        }
+        for (int i = 0; i < kMaxV4; ++i) r.x1[i] = row1[min(lane + kWave * i, c4 - 1)];
     }
 }
 
@@ -1180,13 +1185,13 @@ __device__ __forceinline__ void blank_grad_pairs(const BlankParams &p, int first
     ChainsSeen ps;
     BlankPair<K> r0, r1, r2;
     constexpr int NB = 3;
+    // (loads are issued for indices past the end as well -- they name no pair and load clamped rows: see blank_pair_load
+    // on why the number of loads between a pair and its use must be the same on every path)
     blank_pair_load<K, VEC4>(p, idx, r0, ps);
-    if (idx + stride < total) blank_pair_load<K, VEC4>(p, idx + stride, r1, ps);
+    blank_pair_load<K, VEC4>(p, idx + stride, r1, ps);
 #define CTC_TURN(Q, CUR, NEXT)                                                                                 \
-    if (idx + (Q)*stride < total) {                                                                            \
-        if (idx + ((Q) + NB - 1) * stride < total) blank_pair_load<K, VEC4>(p, idx + ((Q) + NB - 1) * stride, NEXT, ps); \
-        blank_pair_finish<K, VEC4>(p, CUR, occ, gam, stage, tb);                                               \
-    }
+    blank_pair_load<K, VEC4>(p, idx + ((Q) + NB - 1) * stride, NEXT, ps);                                      \
+    if (idx + (Q)*stride < total) blank_pair_finish<K, VEC4>(p, CUR, occ, gam, stage, tb);
     for (; idx < total; idx += NB * stride) {
         CTC_TURN(0, r0, r2)
         CTC_TURN(1, r1, r0)
