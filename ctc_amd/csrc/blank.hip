@@ -831,13 +831,21 @@ __device__ __forceinline__ void blank_row_load(const BlankParams &p, int idx, Bl
     const int lane = lane_id();
     const int q = idx / p.B;
     r.b = __builtin_amdgcn_readfirstlane(idx - q * p.B);     // consecutive waves -> consecutive b: contiguous rows
-    const int2 meta = p.meta[r.b];
+    // (through the scalar cache, and the SAME loads on every path -- dead rows and indices past the end load a clamped
+    // row and ignore it: see blank_pair_load on what a vector load of the lengths or an early exit costs the rows in flight)
+    int2 meta;
+    {
+        unsigned long long bits;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bits) : "s"(p.meta + r.b) : "memory");
+        meta.x = (int)(unsigned)bits;
+        meta.y = (int)(bits >> 32);
+    }
     const int Te = meta.x;                                   // 0 without an alignment: every row is a zero row
     r.Tb = Te;
     r.L = meta.y;
     r.poison = false;
     if (!SYNC) {
-        r.t = q;
+        r.t = q < p.T ? q : -1;
     } else {
         const int m = q >> 1;
         if ((q & 1) == 0) r.t = (m < p.T && (m >= Te || 2 * m >= Te - 1)) ? m : -1;
@@ -845,26 +853,24 @@ __device__ __forceinline__ void blank_row_load(const BlankParams &p, int idx, Bl
         r.t = __builtin_amdgcn_readfirstlane(r.t);
     }
     r.live = r.t >= 0 && r.t < Te;
-    if (!r.live) return;                                     // wave-uniform
+    const int te = r.live ? r.t : 0;
     // (lanes beyond the sample's states: past the end of the buffer, they load nothing and read 0)
-    const int off = r.t * p.NSP * (int)sizeof(float) + (lane * K < 2 * r.L + 1 ? lane * K * (int)sizeof(float) : kPastLattice);
+    const int off = te * p.NSP * (int)sizeof(float) + (lane * K < 2 * r.L + 1 ? lane * K * (int)sizeof(float) : kPastLattice);
     if (SYNC) {
-        if (!wait_chains(p, r.b, r.t + 1, Te - r.t, ps)) { r.poison = true; return; }
+        if (r.live && !wait_chains(p, r.b, r.t + 1, Te - r.t, ps)) r.poison = true;
         agent_load_row<K>(lattice_rsrc(p.al + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), off, r.al);
         agent_load_row<K>(lattice_rsrc(p.be + (int64_t)r.b * p.T * p.NSP, p.T, p.NSP), off, r.be);
     }
-    const int64_t o = ((int64_t)r.b * p.T + r.t) * p.NSP + lane * K;
+    const int64_t o = ((int64_t)r.b * p.T + te) * p.NSP + lane * K;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (!SYNC) { r.al[k] = p.al[o + k]; r.be[k] = p.be[o + k]; r.em[k] = p.em[o + k]; }
     }
     if (VEC4) {
-        const float *row = p.lp + (int64_t)r.t * p.st + (int64_t)r.b * p.sb;
+        const float4 *row = reinterpret_cast<const float4 *>(p.lp + (int64_t)te * p.st + (int64_t)r.b * p.sb);
+        const int c4 = p.C >> 2;
 #pragma unroll
-        for (int i = 0; i < kMaxV4; ++i) {
-            const int q4 = lane + kWave * i;
-            r.xr[i] = q4 < (p.C >> 2) ? reinterpret_cast<const float4 *>(row)[q4] : make_float4(0, 0, 0, 0);
-        }
+        for (int i = 0; i < kMaxV4; ++i) r.xr[i] = row[min(lane + kWave * i, c4 - 1)];   // (past the row: its last float4 again)
     }
 }
 
@@ -1214,12 +1220,11 @@ __device__ __forceinline__ void blank_grad_rows(const BlankParams &p, int first,
     if (!SYNC) {
         BlankRow<K> ra, rb;
         blank_row_load<K, VEC4, SYNC>(p, idx, ra, ps);
-        for (; idx < total_rows; idx += 2 * stride) {
-            const bool has_b = idx + stride < total_rows;    // wave-uniform
-            if (has_b) blank_row_load<K, VEC4, SYNC>(p, idx + stride, rb, ps);
+        for (; idx < total_rows; idx += 2 * stride) {        // (loads past the end name no row: see blank_row_load)
+            blank_row_load<K, VEC4, SYNC>(p, idx + stride, rb, ps);
             blank_row_finish<K, VEC4, SYNC>(p, ra, occ, gam, tb);
-            if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, ra, ps);
-            if (has_b) blank_row_finish<K, VEC4, SYNC>(p, rb, occ, gam, tb);
+            blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, ra, ps);
+            if (idx + stride < total_rows) blank_row_finish<K, VEC4, SYNC>(p, rb, occ, gam, tb);
         }
     } else {
         // fused launch: two waves per SIMD instead of eight, so each keeps six rows in flight (four: +3 %).
@@ -1228,15 +1233,13 @@ __device__ __forceinline__ void blank_grad_rows(const BlankParams &p, int first,
         BlankRow<K> r0, r1, r2, r3, r4, r5;
         constexpr int NB = 6;                                // rows in flight
         blank_row_load<K, VEC4, SYNC>(p, idx, r0, ps);
-        if (idx + stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + stride, r1, ps);
-        if (idx + 2 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, r2, ps);
-        if (idx + 3 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 3 * stride, r3, ps);
-        if (idx + 4 * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + 4 * stride, r4, ps);
+        blank_row_load<K, VEC4, SYNC>(p, idx + stride, r1, ps);
+        blank_row_load<K, VEC4, SYNC>(p, idx + 2 * stride, r2, ps);
+        blank_row_load<K, VEC4, SYNC>(p, idx + 3 * stride, r3, ps);
+        blank_row_load<K, VEC4, SYNC>(p, idx + 4 * stride, r4, ps);
 #define CTC_TURN(Q, CUR, NEXT)                                                                                 \
-    if (idx + (Q)*stride < total_rows) {                                                                       \
-        if (idx + ((Q) + NB - 1) * stride < total_rows) blank_row_load<K, VEC4, SYNC>(p, idx + ((Q) + NB - 1) * stride, NEXT, ps); \
-        blank_row_finish<K, VEC4, SYNC>(p, CUR, occ, gam, tb);                                                 \
-    }
+    blank_row_load<K, VEC4, SYNC>(p, idx + ((Q) + NB - 1) * stride, NEXT, ps);                                 \
+    if (idx + (Q)*stride < total_rows) blank_row_finish<K, VEC4, SYNC>(p, CUR, occ, gam, tb);
         for (; idx < total_rows; idx += NB * stride) {
             CTC_TURN(0, r0, r5)
             CTC_TURN(1, r1, r0)
