@@ -201,14 +201,27 @@ def eager_python_step(wl, iters=300):
         else:
             loss = ctc_amd.CTCLoss.apply(x, wl.tg, wl.il, wl.tl)
         loss.backward()
-    for _ in range(30):
-        one()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        one()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters * 1e6
+    def floor():                                             # the cheapest loss torch itself offers on the same tensor:
+        x.grad = None                                        # what one eager forward + backward() costs before any CTC
+        x.sum().backward()
+
+    def forward_only():
+        with torch.no_grad():
+            if wl.variant == "blank":
+                F.blank_ctc_loss(x, wl.tg, wl.il, wl.tl)
+            else:
+                ctc_amd.CTCLoss.apply(x, wl.tg, wl.il, wl.tl)
+
+    def timed(fn):
+        for _ in range(30):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e6
+    return timed(one), timed(floor), timed(forward_only)
 
 
 def main():
@@ -413,9 +426,13 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and not a.no_eager_python:
-            out["eager_python"] = {"us_per_step": round(eager_python_step(wl, 300 if variant != "blank" else 20), 2),
+            step_us, floor_us, fwd_us = eager_python_step(wl, 300 if variant != "blank" else 20)
+            out["eager_python"] = {"us_per_step": round(step_us, 2),
                                    "launch": "eager-python",
-                                   "what": "CTCLoss.apply(...) + loss.backward() issued eagerly (train.py:427,444), host-inclusive"}
+                                   "what": "CTCLoss.apply(...) + loss.backward() issued eagerly (train.py:427,444), host-inclusive",
+                                   "torch_floor_us": round(floor_us, 2),
+                                   "torch_floor_what": "x.sum().backward() on the same tensor, same loop: the autograd engine's own cost per eager step",
+                                   "forward_only_us": round(fwd_us, 2)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
