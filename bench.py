@@ -410,6 +410,9 @@ def main():
         }
         if bucketed is not None:
             out["bucketed"] = bucketed
+        # (before anything multi-threaded runs on the host: the checker's OpenMP workers keep spinning for a while after
+        # their last parallel region and the autograd engine's thread wake-ups then take 2-3x as long)
+        eager = eager_python_step(wl, 300 if variant != "blank" else 20) if (world == 1 and not a.no_eager_python) else None
         # parity of THIS batch against the float64 oracle (untimed)
         ref = oracle_step(wl, threads=min(16, os.cpu_count() or 1), dtype=np.float64)
         torch.cuda.synchronize()
@@ -425,8 +428,8 @@ def main():
                 out["cpu_baseline_torch"] = torch_cpu_ctc_baseline(wl, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not a.no_eager_python:
-            step_us, floor_us, fwd_us = eager_python_step(wl, 300 if variant != "blank" else 20)
+        if eager is not None:
+            step_us, floor_us, fwd_us = eager
             out["eager_python"] = {"us_per_step": round(step_us, 2),
                                    "launch": "eager-python",
                                    "what": "CTCLoss.apply(...) + loss.backward() issued eagerly (train.py:427,444), host-inclusive",
