@@ -1388,12 +1388,12 @@ static int run_blank(BlankParams &p, hipStream_t s)
 
     // Persistent launch.  Hard conditions: a gradient is wanted, every workgroup resident with at least as
     // many workers as chains, 32-bit row offsets.  Where it PAYS was measured (tools/blank_sweep.py, T = 1000,
-    // us per call persistent / three launches): B=64 C=1000 S=100 234/299, 64x500x100 189/243, 32x1000x100
-    // 182/211, 48x640x100 200/232, 64x800x200 368/498, 64x200x100 190/213 -- but 16x1000x100 180/174,
-    // 96x1000x100 425/411 (the chains take too many CUs from the workers), 64x1000x30 196/199, 64x400x30
-    // 145/148, 32x400x30 132/119 (two states per lane: the plain chain kernel is fast), 32x2000x50 373/294
-    // (rows too wide for the float4 loaders); over T at 64x1000x100: 50/53 at 128, 75/84 at 256, 122/150 at
-    // 512.  ctc_amd_blank_set_schedule(1 / 0) forces / forbids it (tests, measurements).
+    // us per call persistent / three launches, round 2 -- half of the lattice in memory): B=64 C=1000 S=100 220/296,
+    // 64x500x100 180/238, 32x1000x100 170/201, 48x640x100 184/229, 64x800x200 289/524, 64x200x100 184/203,
+    // 96x1000x100 378/432, 128x1000x100 436/521, 24x1000x100 174/189 -- but 16x1000x100 169/164 (too little
+    // bandwidth work per step), 64x1000x30 192/194 and 64x400x30 138/140 (two states per lane: a tie), 32x400x30
+    // 132/111, 32x2000x50 352/285 (rows too wide for the float4 loaders); over T at 64x1000x100: 51.5/51.8 at 128,
+    // 74/82 at 256, 119/146 at 512.  ctc_amd_blank_set_schedule(1 / 0) forces / forbids it (tests, measurements).
     const int schedule = blank_schedule();
     const bool forced = schedule == 1, forbidden = schedule == 0;
     if (p.grad && !forbidden && p.T >= kFusedMinT && (int64_t)p.T * p.NSP * 4 < kPastLattice &&
@@ -1405,7 +1405,7 @@ static int run_blank(BlankParams &p, hipStream_t s)
         if (lds < kFusedWaves * worker_lds) lds = kFusedWaves * worker_lds;
         if (lds < kMaxLds / 2 + 1024) lds = kMaxLds / 2 + 1024;
         const int cap = lds <= kMaxLds ? (vec4 ? fused_capacity<K, true>(lds) : fused_capacity<K, false>(lds)) : 0;
-        const bool pays = K >= 4 && vec4 && p.T >= 2 * kFusedMinT && 8 * p.B >= cap && 4 * p.B <= cap &&
+        const bool pays = K >= 4 && vec4 && p.T >= 2 * kFusedMinT && 11 * p.B >= cap && 2 * p.B <= cap &&
                           (int64_t)p.B * p.C >= 16384;
         if (cap >= 2 * p.B && cap - p.B >= 32 && (pays || forced)) {
             int rc = launch<blank_tables_kernel>(dim3(p.B), dim3(256), p.NSP * sizeof(int), s, p);

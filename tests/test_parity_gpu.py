@@ -366,7 +366,7 @@ def test_blank_nonzero_blank_index_and_wide_rows(dev, shape, monkeypatch):  # to
 
 
 def test_blank_persistent_launch_is_the_default_for_config5_like_batches(dev, monkeypatch):
-    """B = #CUs/8 .. #CUs/4, 4 states per lane, float4 rows, T >= 256: the library takes the persistent launch by
+    """B = #CUs/11 .. #CUs/2, 4 states per lane, float4 rows, T >= 256: the library takes the persistent launch by
     itself; the result must agree with the three launches to rounding and with the float64 oracle"""
     import ctc_amd
     T, B, C, S = 260, 32, 512, 100
@@ -382,7 +382,7 @@ def test_blank_persistent_launch_is_the_default_for_config5_like_batches(dev, mo
     d = np.abs(auto["grad"] - three["grad"]).max()
     assert d < 4e-6
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    if cus // 8 <= B <= cus // 4:                     # (the rule of run_blank, blank.hip)
+    if 11 * B >= cus and 2 * B <= cus:                # (the rule of run_blank, blank.hip)
         assert d > 0.0          # different schedules (beta is stored without its emission): close, not identical
 
 

@@ -42,5 +42,5 @@ for T in Ts:
     for mode in ("1", "0"):
         ctc_amd.set_blank_schedule(int(mode))
         t[mode] = timed(T)
-ctc_amd.set_blank_schedule(-1)
     print("B=%d C=%d S=%d T=%5d: persistent launch %8.1f us, three launches %8.1f us per call" % (B, C, S, T, t["1"], t["0"]))
+ctc_amd.set_blank_schedule(-1)
