@@ -489,6 +489,59 @@ def test_noblank_r16_small_shape_sweep(dev):
         assert_close(r, ref, 2e-6 * 256.0 / B)
 
 
+def test_binary_pipelined_kernel_shape_sweep(dev):
+    """Seeded sweep over shapes the pipelined binary kernel takes (S <= 64, T <= 168, C <= 256, images in LDS): every
+    number of rounds and emission tiles, 1..4 column chunks, 1..4 label tiles, ragged T_b (down to L_b), soft
+    targets on every other case, scaled logits on every third (rows that leave the cheap range)."""
+    import ctc_amd
+    rng = np.random.RandomState(11)
+    for case in range(40):
+        T = int(rng.randint(1, 169))
+        B = int(rng.randint(1, 5))
+        C = int(rng.randint(1, 257))
+        S = int(rng.randint(1, 65))
+        if (3 * T + 8) * ((S + 3) // 4 * 4) + 96 + T + (S + T + 4) * (C + 40) > 40000:   # keep the images inside 160 KB
+            C = min(C, 64)
+        x, y, Tb, L = synth_binary(2000 + case, T, B, C, S, var_T=True, density=0.15)
+        L = torch.minimum(L, Tb)
+        if case % 2:
+            y = y * torch.rand(y.shape, generator=torch.Generator().manual_seed(case))
+        if case % 3 == 0:
+            x = x * 5.0
+        ref = ctc_c.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float64)
+        ref32 = ctc_c.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float32)
+        r = run_hip(ctc_amd.binary_ctc_loss, x, y, Tb, L, dev)
+        tol = max(2e-7 * max(1.0, 256.0 / B), 2.0 * np.abs(ref32["grad"] - ref["grad"]).max())
+        assert np.isfinite(r["grad"]).all(), (case, T, B, C, S)
+        assert np.abs(r["grad"] - ref["grad"]).max() <= tol, (case, T, B, C, S)
+        # (nll against the float32 port: with |x| up to 20 the reference's own fp32 arithmetic -- p rounding to 1, the
+        # -100 clamp -- is 1 % away from float64, and that arithmetic is what the kernel reproduces)
+        assert (np.abs(r["nll"] - ref32["nll"]) <= 1e-4 * np.maximum(1.0, np.abs(ref32["nll"]))).all(), (case, T, B, C, S)
+        if case % 3:
+            assert (np.abs(r["nll"] - ref["nll"]) <= 3e-5 * np.maximum(1.0, np.abs(ref["nll"]))).all(), (case, T, B, C, S)
+
+
+def test_blank_persistent_launch_shape_sweep(dev, monkeypatch):
+    """Seeded sweep with the persistent launch forced: T from its minimum up, ragged T_b and L_b, 2 / 4 / 8 states per
+    lane, float4 and scalar rows -- against the float64 oracle."""
+    import ctc_amd
+    _schedule(monkeypatch, 1)
+    rng = np.random.RandomState(13)
+    for case in range(12):
+        T = int(rng.randint(128, 400))
+        B = int(rng.randint(1, 9))
+        S = int([12, 40, 100, 130, 250][rng.randint(0, 5)])
+        C = int([37, 64, 260, 1001][rng.randint(0, 4)])
+        lp, tgt, Tb, L = synth_blank(3000 + case, T, B, C, S, var_T=True)
+        ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64, threads=8)
+        fin = np.isfinite(ref["nll"])
+        r = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
+        assert (np.isinf(r["nll"]) == ~fin).all(), (case, T, B, C, S)
+        if fin.any():
+            assert np.abs(r["nll"][fin] - ref["nll"][fin]).max() <= 1e-5 * max(1.0, np.abs(ref["nll"][fin]).max()), (case, T, B, C, S)
+            assert np.abs(r["grad"][:, fin] - ref["grad"][:, fin]).max() < min(1e-4, 2e-6 * 64.0 / B * max(1.0, T / 300.0)), (case, T, B, C, S)
+
+
 def test_noblank_extreme_logits_keep_full_range(dev):
     """State contrasts far beyond fp32 range (logits x 200: per-sample nll ~ 1e5) -- the lattice
     cells carry their own exponents, so nothing underflows and nothing is approximated."""
