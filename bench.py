@@ -69,6 +69,12 @@ def parse():
     ap.add_argument("--loss-bucket", type=int, default=None,
                     help="N>1: steps per RCCL all-reduce of the loss scalars (default 1 = one all-reduce per step)")
     ap.add_argument("--no-eager-python", action="store_true", help="skip the secondary CTCLoss.apply + backward() timing")
+    ap.add_argument("--collective-launch", default="graph", choices=["graph", "eager"],
+                    help="N>1, one all-reduce per step: graph = the asynchronous all-reduce of every step is captured into "
+                         "the hipGraph with the step (RCCL supports capture); eager = steps and collectives issued one by one "
+                         "from Python (host-bound: ~22 us per torch.distributed call)")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="with --gpus 1: create a one-rank process group and run the N>1 code path (all-reduce per step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 collective backend: nccl = RCCL over xGMI; gloo only to rehearse the multi-rank "
                          "path on a box with fewer GPUs than ranks (ranks then share devices)")
@@ -238,12 +244,19 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    import datetime
+    coll = world > 1 or a.rehearse_collective               # the step is followed by a loss all-reduce
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        # (a stuck collective ends the run after three minutes instead of hanging it)
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
 
     variant = a.variant
     K = a.steps if a.steps is not None else (500 if variant != "blank" else 30)
@@ -262,11 +275,13 @@ def main():
 
     # N>1 default: ONE all-reduce per step (BASELINE north_star), eager launches so that the
     # collective can be issued behind each step; N=1 / explicit buckets: steps replayed from hipGraphs
-    bucket = a.loss_bucket if a.loss_bucket is not None else (1 if world > 1 else None)
-    per_step_collective = world > 1 and bucket == 1
-    launch = "eager" if per_step_collective else a.launch
+    bucket = a.loss_bucket if a.loss_bucket is not None else (1 if coll else None)
+    per_step_collective = coll and bucket == 1
+    # one all-reduce per step INSIDE the hipGraph (asynchronous: it runs on RCCL's stream beside the next step's kernel)
+    in_graph = per_step_collective and a.launch == "graph" and a.collective_launch == "graph" and a.backend == "nccl"
+    launch = "graph" if in_graph else ("eager" if per_step_collective else a.launch)
     M = max(1, min(a.graph_steps, K)) if launch == "graph" else 1
-    if bucket is None or (launch == "graph" and world > 1):
+    if bucket is None or (launch == "graph" and coll and not in_graph):
         bucket = M if launch == "graph" else (bucket or 1)
 
     # ---- the step sequence, eager or captured into hipGraphs (two, alternating, so that an
@@ -276,38 +291,61 @@ def main():
     wl.step(rings[0].data_ptr(), ws, cur_stream(dev))       # first touch outside any capture
     torch.cuda.synchronize()
 
-    def capture(m):
+    def capture(m, collective=False):
         gs = []
         for r in rings:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 s = cur_stream(dev)
+                works = []
                 for j in range(m):
                     wl.step(r.data_ptr() + 4 * j, ws, s)
+                    if collective:
+                        works.append(dist.all_reduce(r[j:j + 1], op=dist.ReduceOp.SUM, async_op=True))
+                for w in works:                             # (joins RCCL's stream back into the capture)
+                    w.wait()
             gs.append(g)
         return gs
 
-    graphs = capture(M) if launch == "graph" else []
+    if coll:                                                # communicator set up outside any capture
+        dist.all_reduce(rings[0][:1], op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        rings[0].zero_()
+    graphs = []
+    if in_graph:
+        try:
+            graphs = capture(M, collective=True)
+            graphs[0].replay()
+            torch.cuda.synchronize()
+        except Exception as e:                              # noqa: BLE001 -- any failure: the eager path still works
+            print("bench: collective capture failed (%s: %s); issuing steps and all-reduces eagerly"
+                  % (type(e).__name__, str(e)[:200]), file=sys.stderr)
+            in_graph, launch, M, graphs = False, "eager", 1, []
+            bucket = 1
+    elif launch == "graph":
+        graphs = capture(M)
     pending = [None, None]
     state = {"i": 0}
 
-    def run_steps(n, launch=launch, graphs=graphs, M=M, bucket=bucket):
-        """exactly n steps; N>1: loss contributions all-reduced every `bucket` steps"""
+    def run_steps(n, launch=launch, graphs=graphs, M=M, bucket=bucket, graph_collective=in_graph):
+        """exactly n steps; N>1: loss contributions all-reduced every `bucket` steps (graph_collective: the graphs
+        carry one asynchronous all-reduce per step themselves)"""
         done = 0
         while done < n:
             k = state["i"] & 1
             if pending[k] is not None:                      # ring k is about to be overwritten
                 pending[k].wait()
                 pending[k] = None
-            if launch == "graph" and n - done >= M:
+            replayed = launch == "graph" and n - done >= M
+            if replayed:
                 graphs[k].replay()
                 m = M
             else:
-                m = min(bucket, n - done) if launch == "eager" else n - done
+                m = min(bucket, n - done) if (launch == "eager" or graph_collective) else n - done
                 s = cur_stream(dev)
                 for j in range(m):
                     wl.step(rings[k].data_ptr() + 4 * j, ws, s)
-            if world > 1:
+            if coll and not (replayed and graph_collective):
                 pending[k] = dist.all_reduce(rings[k][:max(m, 1)], op=dist.ReduceOp.SUM, async_op=True)
             state["i"] += 1
             done += m
@@ -348,9 +386,9 @@ def main():
     if per_step_collective and a.launch == "graph":
         Mb = max(1, min(a.graph_steps, K))
         gb = capture(Mb)
-        run_steps(Mb, launch="graph", graphs=gb, M=Mb, bucket=Mb)
+        run_steps(Mb, launch="graph", graphs=gb, M=Mb, bucket=Mb, graph_collective=False)
         nb = max(Mb, K // Mb * Mb)
-        elb = timed(nb, launch="graph", graphs=gb, M=Mb, bucket=Mb)
+        elb = timed(nb, launch="graph", graphs=gb, M=Mb, bucket=Mb, graph_collective=False)
         bucketed = {"value": round(B_total(world, wl, a) * nb / elb, 1), "unit": "samples/s", "steps": nb,
                     "ms_per_step": round(elb / nb * 1e3, 6), "launch": "graph", "graph_steps": Mb,
                     "loss_allreduce_bucket": Mb}
@@ -394,9 +432,12 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.name, "variant": variant, "per_gpu_batch": B, "global_batch": Bg,
                        "T": wl.T, "C": wl.C, "S": wl.S, "parallelism": "dp%d (batch-sharded)" % world,
-                       "collective": (a.backend if world > 1 else None),
+                       "collective": (a.backend if coll else None),
+                       "collective_launch": (("in the hipGraph, one asynchronous all-reduce per step" if in_graph else
+                                              "eager, one asynchronous all-reduce per step" if per_step_collective else
+                                              "one all-reduce per %d steps" % bucket) if coll else None),
                        "launch": launch, "graph_steps": M if launch == "graph" else None,
-                       "loss_allreduce_bucket": bucket if world > 1 else None,
+                       "loss_allreduce_bucket": bucket if coll else None,
                        "timed_repeats_median_of": repeats,
                        "step": "fused loss+grad launch + scale_grad launch (loss.backward(), grad_out=1)"},
             "lattice_cells_per_sec": round(wl.cells * (Bg / B) * K / el, 1),
@@ -436,8 +477,9 @@ def main():
                                    "torch_floor_us": round(floor_us, 2),
                                    "torch_floor_what": "x.sum().backward() on the same tensor, same loop: the autograd engine's own cost per eager step",
                                    "forward_only_us": round(fwd_us, 2)}
-    if world > 1:
-        dist.barrier()
+    if coll:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
