@@ -73,6 +73,9 @@ def parse():
                     help="N>1, one all-reduce per step: graph = the asynchronous all-reduce of every step is captured into "
                          "the hipGraph with the step (RCCL supports capture); eager = steps and collectives issued one by one "
                          "from Python (host-bound: ~22 us per torch.distributed call)")
+    ap.add_argument("--watchdog-seconds", type=int, default=900,
+                    help="end the process (exit code 3) if the run has not finished by then: a collective inside a "
+                         "hipGraph that never completes is invisible to torch.distributed's own watchdog")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="with --gpus 1: create a one-rank process group and run the N>1 code path (all-reduce per step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -232,6 +235,15 @@ def eager_python_step(wl, iters=300):
 
 def main():
     a = parse()
+    if a.watchdog_seconds > 0:
+        import threading
+
+        def _give_up():
+            print("bench: not finished after %d s, giving up" % a.watchdog_seconds, file=sys.stderr, flush=True)
+            os._exit(3)
+        wd = threading.Timer(a.watchdog_seconds, _give_up)
+        wd.daemon = True
+        wd.start()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
