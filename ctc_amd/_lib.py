@@ -9,6 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("CTC_AMD_LIB") or os.path.join(_HERE, "lib", "libctc_amd.so")   # override: kernel experiments
 
 NOBLANK, BINARY, BLANK = 0, 1, 2
+ABI_VERSION = 2                     # CTC_AMD_ABI_VERSION of include/ctc_amd.h this binding was written for
+ERR_CODE_OVERFLOW = -3
 
 _vp, _i64, _int, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -26,7 +28,7 @@ PROTOTYPES = {
     "ctc_amd_blank_loss_grad": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int,
                                        _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctc_amd_scale_grad": (_int, [_vp, _vp, _sz, _vp]),
-    "ctc_amd_dedup_multihot_targets": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp]),
+    "ctc_amd_dedup_multihot_targets": (_int, [_vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ctc_amd_blank_set_schedule": (_int, [_int]),
     "ctc_amd_workspace_status": (_int, [_vp, _int, _vp, ctypes.POINTER(ctypes.c_uint)]),
     "ctc_amd_noblank_best_path": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _int,
@@ -56,8 +58,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.ctc_amd_abi_version() != 1:
-        raise CtcAmdError("ctc_amd: ABI version mismatch")
+    if lib.ctc_amd_abi_version() != ABI_VERSION:
+        raise CtcAmdError("ctc_amd: %s has ABI version %d, this binding needs %d -- rebuild with "
+                          "`python -m ctc_amd.build --force`" % (SO_PATH, lib.ctc_amd_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

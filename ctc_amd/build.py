@@ -39,6 +39,10 @@ def build(force=False, verbose=False, extra_flags=(), name=None):
     -DCTC_AMD_DIAGNOSTICS -> lib/libctc_amd_diag.so, the library tools/ load (phase stamps, forced kernel
     choices, the chain probe); any other name/flags: a variant for A/B runs or fault injection."""
     so = SO if name is None else os.path.join(LIBDIR, "libctc_amd_%s.so" % name)
+    if name is None and any(f.startswith(("-DCTC_X_", "-DCTC_AMD_EXPERIMENTS", "-DCTC_AMD_FAULT_INJECT",
+                                          "-DCTC_AMD_DIAGNOSTICS")) for f in extra_flags):
+        raise RuntimeError("ctc_amd.build: experiment / diagnostics / fault-injection flags %s are refused for the "
+                           "product library -- give the variant a name" % (list(extra_flags),))
     if name is None and not force and not _stale():
         return so
     os.makedirs(LIBDIR, exist_ok=True)
@@ -67,6 +71,15 @@ def build(force=False, verbose=False, extra_flags=(), name=None):
 
 def build_diag(verbose=False):
     return build(force=True, verbose=verbose, extra_flags=("-DCTC_AMD_DIAGNOSTICS",), name="diag")
+
+
+def build_fault(verbose=False):
+    """The fault-injection variant tests/test_status.py drives (-DCTC_AMD_FAULT_INJECT -> lib/libctc_amd_fault.so):
+    built here, with the product library, so that the GPU run compiles nothing."""
+    so = os.path.join(LIBDIR, "libctc_amd_fault.so")
+    if os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(build()):
+        return so
+    return build(force=True, verbose=verbose, extra_flags=("-DCTC_AMD_FAULT_INJECT",), name="fault")
 
 
 if __name__ == "__main__":

@@ -15,6 +15,9 @@ extern "C" const char *ctc_amd_error_string(int code)
         case 0: return "success";
         case CTC_AMD_ERR_BAD_ARGUMENT: return "ctc_amd: bad argument (null pointer or non-positive size)";
         case CTC_AMD_ERR_UNSUPPORTED_SHAPE: return "ctc_amd: shape not supported by the gfx950 kernels";
+        case CTC_AMD_ERR_CODE_OVERFLOW:
+            return "ctc_amd: more than 64 classes in the reference's int32 row codes (the reference raises OverflowError "
+                   "at 2**64): pass exact_rows";
         default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "ctc_amd: unknown error";
     }
 }

@@ -3,6 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Compile-time experiment switches (-DCTC_X_*: ablations and measured-and-dropped variants) change
+// what the kernels compute or skip.  They exist for A/B builds only (tools/build_variant.sh) and need
+// -DCTC_AMD_EXPERIMENTS beside them; ctc_amd/build.py refuses both for the product library's name, so a
+// stray -D in the environment cannot ship a library that leaves out the batch sum or the status word.
+#if !defined(CTC_AMD_EXPERIMENTS) &&                                                                            \
+    (defined(CTC_X_NOSTATUS) || defined(CTC_X_NOREDUCE) || defined(CTC_X_NORETURN) || defined(CTC_X_NOCHAIN) || \
+     defined(CTC_X_NOPRIO) || defined(CTC_X_NOREAD) || defined(CTC_X_NOWRITE) || defined(CTC_X_FULL_LATTICE) || \
+     defined(CTC_X_GATHER_ONCE))
+#error "CTC_X_* experiment switches need -DCTC_AMD_EXPERIMENTS (A/B builds only, never the product library)"
+#endif
+
 namespace ctc {
 
 constexpr int kWave = 64;
@@ -248,21 +259,24 @@ __device__ __forceinline__ int load_label(const void *p, int is64, int64_t i)
     return static_cast<const int32_t *>(p)[is64 ? 2 * i : i];
 }
 
-// Two int64 values at wave-uniform addresses through the scalar memory path (s_load_dwordx2): issued
-// at construction, waited for in get().  The compiler does not know about the loads in flight, so
-// get() ties the values to the wait (they must not be read before it).
+// Two int64 values at wave-uniform addresses through the scalar memory path (s_load_dwordx2): loaded through
+// constant-address-space pointers, so the COMPILER emits the scalar loads and tracks them (its own
+// s_waitcnt lgkmcnt in front of the first use; a hand-written asm load would leave the destination SGPRs
+// "defined" while the load is still in flight, free for the register allocator to copy or spill).  A plain
+// global load of a uniform address becomes a vector load + readfirstlane instead: a memory round trip in
+// front of everything that follows, and every later wait on the row loads degrades to vmcnt(0).
 struct ScalarLengths {
-    unsigned long long a, b;
+    int64_t a, b;
     __device__ __forceinline__ ScalarLengths(const int64_t *pa, const int64_t *pb)
     {
-        asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0" : "=&s"(a), "=&s"(b) : "s"(pa), "s"(pb));
+        typedef const __attribute__((address_space(4))) int64_t const_i64;
+        a = *(const_i64 *)(uintptr_t)pa;
+        b = *(const_i64 *)(uintptr_t)pb;
     }
     __device__ __forceinline__ void get(int64_t &va, int64_t &vb) const
     {
-        unsigned long long x = a, y = b;
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x), "+s"(y));
-        va = (int64_t)x;
-        vb = (int64_t)y;
+        va = a;
+        vb = b;
     }
 };
 
@@ -338,18 +352,25 @@ __device__ __forceinline__ void publish_and_reduce(float value, int b, int B, fl
 // (nll store -> acknowledgement -> ticket -> last arriver reads every nll -> loss), which cost the
 // kernel its tail through queues full of gradient stores (config 2: 13.2 us with, 12.1 us without).
 // Every workgroup makes ONE returning 64-bit atomic add to a packed word
-//     [63:52] arrivals   [51:40] arrivals that did not fit   [39:0] sum of value * 2^16 (fixed point);
+//     [63:52] arrivals   [51:40] arrivals that did not fit   [39:0] sum of value * 2^F (fixed point);
 // integer adds commute, so whoever completes a word holds its exact sum: bitwise the same from run to
-// run, exact to 2^-17 per sample.  Atomics on ONE word are served at ~90 per us (256 workgroups
+// run, exact to 2^-(F+1) per sample.  F depends on B alone (every workgroup must use the same): a value
+// fits when it is below 2^13 = 8192, so B of them need 13 + ceil(log2 B) integer bits and F = 27 -
+// ceil(log2 B) (B = 256: 19 bits, one sample's rounding 9.5e-7; B = 4095: 15 bits; never below the fp32
+// resolution of an nll >= 16 at B <= 256).  Atomics on ONE word are served at ~90 per us (256 workgroups
 // finishing together wait 2.8 us for each other), so the words are SHARDED: sample b adds to shard
 // b % 16, the workgroup that completes a shard adds the shard's word to the top word, and the one that
 // completes the top word writes the loss.  The nll output is a write-through store nobody waits for.
-// A value that does not fit (value * B >= 2^24, negative, NaN, inf: the infeasible sentinel 1e13, a
+// A value that does not fit (value >= 8192, negative, NaN, inf: the infeasible sentinel 1e13, a
 // starved hand-off) takes the slow way for ITSELF only -- store, acknowledgement, its index into a
 // list, acknowledgement, then the packed add counting it as "did not fit" -- and the finisher adds those
 // from memory (in double).  B > 4095: the ticket form.
 // Workspace: bytes [16,24) top word, [24,28) list length, [256,512) shard words, [512, 512 + 4 B) the list.
-constexpr int kAccFracBits = 16, kAccMaxB = 4095, kAccShards = 16;
+constexpr int kAccIntBits = 13, kAccMaxB = 4095, kAccShards = 16;
+__device__ __forceinline__ int acc_frac_bits(int B)          // 40 - 13 - ceil(log2 B), B in [1, 4095]
+{
+    return 40 - kAccIntBits - (B <= 1 ? 0 : 32 - __builtin_clz((unsigned)(B - 1)));
+}
 __host__ __device__ inline size_t acc_list_bytes(int B) { return 256 + (((size_t)4 * B + 255) & ~(size_t)255); }
 __device__ __forceinline__ void publish_and_reduce_sum(float value, int b, int B, float *nll, float *loss,
                                                        float loss_scale, unsigned *counter)
@@ -364,8 +385,9 @@ __device__ __forceinline__ void publish_and_reduce_sum(float value, int b, int B
     unsigned *nlist = counter + 6, *list = counter + 128;
     __hip_atomic_store(&nll[b], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long add = 1ull << 52;
-    if (value >= 0.f && value * (float)B < 16777216.f) {
-        add += (unsigned long long)__double2ull_rn((double)value * (double)(1 << kAccFracBits));
+    const int frac = acc_frac_bits(B);
+    if (value >= 0.f && value < (float)(1 << kAccIntBits)) {
+        add += (unsigned long long)__double2ull_rn((double)value * (double)(1u << frac));
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this value is in memory ...
         const unsigned slot = __hip_atomic_fetch_add(nlist, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -386,7 +408,7 @@ __device__ __forceinline__ void publish_and_reduce_sum(float value, int b, int B
     old = __hip_atomic_fetch_add(top, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((old >> 52) + (add >> 52) != (unsigned long long)B) return;
     const unsigned long long tot = old + add;
-    double s = (double)(tot & ((1ull << 40) - 1)) * (1.0 / (double)(1 << kAccFracBits));
+    double s = (double)(tot & ((1ull << 40) - 1)) * (1.0 / (double)(1u << frac));
     const unsigned nsp = (unsigned)(tot >> 40) & 0xfffu;
     for (unsigned i = 0; i < nsp; ++i) {
         const unsigned bb = __hip_atomic_load(&list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

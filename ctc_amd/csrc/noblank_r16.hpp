@@ -774,6 +774,8 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 }
 
 // ---- diagnostic probe (tools/chain_probe.py): the chains alone, every row already published ------
+// (diagnostics build only: the product library carries no kernel it never launches)
+#ifdef CTC_AMD_DIAGNOSTICS
 __global__ __launch_bounds__(kThreads, 4) void r16_chain_probe_kernel(NoblankParams p, unsigned long long *out, int waves_alive)
 {
     extern __shared__ float4 smem_raw[];
@@ -797,5 +799,6 @@ __global__ __launch_bounds__(kThreads, 4) void r16_chain_probe_kernel(NoblankPar
         out[4 + w] = (unsigned long long)cell_k(c);
     }
 }
+#endif  // CTC_AMD_DIAGNOSTICS
 
 }  // namespace ctc

@@ -187,45 +187,48 @@ def _launch(variant, x, targets, in_len, tgt_len, want_grad, batch_total, blank=
     il = _lengths(in_len, B, "input_lengths", dev, T)
     tl = _lengths(tgt_len, B, "target_lengths", dev, S, lo=0 if variant == _lib.BLANK else 1)
     scale = 1.0 / (B if batch_total is None else int(batch_total))
-    out = torch.empty(B + 1, dtype=torch.float32, device=dev)       # nll[B] and the loss behind it: one allocation
+    # nll and the loss are tensors of their own, not views of one buffer: autograd refuses in-place arithmetic
+    # on a view returned by a custom Function (`loss /= accum_steps`, `loss += aux` in a training loop)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
     grad = torch.empty((T, B, C), dtype=torch.float32, device=dev) if want_grad else None
     lib = _lib.load()
     with _on_device(dev):
         stream = _stream_handle(dev)
         ws = _workspace(variant, T, B, C, S, dev, stream)
         gp = grad.data_ptr() if want_grad else None
-        op = out.data_ptr()
+        op, lp_ = nll.data_ptr(), loss.data_ptr()
         if variant == _lib.NOBLANK and label_smoothing is not None:
             rc = lib.ctc_amd_noblank_smoothed_loss_grad(
                 xs.data_ptr(), st, sb, tg.data_ptr(), int(tg.dtype is torch.int64),
                 il.data_ptr(), tl.data_ptr(), T, B, C, S, float(label_smoothing), scale, scale,
-                op, op + 4 * B, gp, ws.data_ptr(), stream)
+                op, lp_, gp, ws.data_ptr(), stream)
             if rc:
                 _lib.check(rc, "ctc_amd_noblank_smoothed_loss_grad")
         elif variant == _lib.NOBLANK:
             rc = lib.ctc_amd_noblank_loss_grad(
                 xs.data_ptr(), st, sb, tg.data_ptr(), int(tg.dtype is torch.int64),
                 il.data_ptr(), tl.data_ptr(), T, B, C, S, scale, scale,
-                op, op + 4 * B, gp, ws.data_ptr(), stream)
+                op, lp_, gp, ws.data_ptr(), stream)
             if rc:
                 _lib.check(rc, "ctc_amd_noblank_loss_grad")
         elif variant == _lib.BINARY:
             rc = lib.ctc_amd_binary_loss_grad(
                 xs.data_ptr(), st, sb, tg.data_ptr(),
                 il.data_ptr(), tl.data_ptr(), T, B, C, S, scale, scale,
-                op, op + 4 * B, gp, ws.data_ptr(), stream)
+                op, lp_, gp, ws.data_ptr(), stream)
             if rc:
                 _lib.check(rc, "ctc_amd_binary_loss_grad")
         else:
             rc = lib.ctc_amd_blank_loss_grad(
                 xs.data_ptr(), st, sb, tg.data_ptr(), int(tg.dtype is torch.int64),
                 il.data_ptr(), tl.data_ptr(), T, B, C, S, int(blank), scale, scale,
-                op, op + 4 * B, gp, ws.data_ptr(), stream)
+                op, lp_, gp, ws.data_ptr(), stream)
             if rc:
                 _lib.check(rc, "ctc_amd_blank_loss_grad")
     if _VALIDATE:
         check_status(dev)
-    return out[B], out[:B], grad
+    return loss, nll, grad
 
 
 def _scaled_grad(ctx, gout):
@@ -386,25 +389,34 @@ def noblank_posteriors(logits, targets, input_lengths, target_lengths):
     return gamma, nll
 
 
-def dedup_multihot_targets(rows):
-    """Target construction on the device (datasets/charades_ctc_next_pred.py:653-682).
+def dedup_multihot_targets(rows, exact_rows=False):
+    """Target construction on the device (datasets/charades_ctc_next_pred.py:646-651,663-678).
 
     ``rows`` [B,S,C] integer multi-hot label rows (one row per annotated time step of a clip) ->
-    ``(targets [B,S,C] int32, lengths [B] int64)``: the distinct non-empty rows in order of first
+    ``(targets [B,S,C] int32, lengths [B] int64)``: the rows whose code is new, in order of first
     appearance, padded with rows of -1 (the block the reference stores as ``o_only_target`` /
-    ``o_target_length``).  ``targets.clamp(min=0).float()`` is the [B,S,C] float input of NoBlankBinaryCTC."""
+    ``o_target_length``).  ``targets.clamp(min=0).float()`` is the [B,S,C] float input of NoBlankBinaryCTC.
+
+    Default (``exact_rows=False``): the reference's own comparison -- the int32 code ``sum_o row[o] * 2**o``
+    as torch accumulates it into an IntTensor (class 31 is the sign bit, classes 32..63 drop out, code 0
+    never enters); bit-exact with the reference at its default 38 / 33 classes (opts.py:60-61).  With more
+    than 64 classes the reference raises OverflowError (``2**64``), and so does this.  ``exact_rows=True``
+    compares whole rows instead (any C)."""
     _require_hip(rows, "rows")
     if rows.dim() != 3 or rows.dtype.is_floating_point:
         raise ValueError("ctc_amd: rows must be an integer tensor [B,S,C], got %s %s" % (tuple(rows.shape), rows.dtype))
     B, S, C = rows.shape
     if B < 1 or S < 1 or C < 1:
         raise ValueError("ctc_amd: empty rows %s" % (tuple(rows.shape),))
+    if not exact_rows and C > 64:
+        raise OverflowError("ctc_amd: int too big to convert -- the reference's row code 2**o does not exist for "
+                            "class o >= 64 (C = %d); pass exact_rows=True" % C)
     r = rows if rows.dtype is torch.int32 and rows.is_contiguous() else rows.to(torch.int32).contiguous()
     out = torch.empty_like(r)
     length = torch.empty(B, dtype=torch.int64, device=r.device)
     with _on_device(r.device):
-        rc = _lib.load().ctc_amd_dedup_multihot_targets(r.data_ptr(), B, S, C, out.data_ptr(), length.data_ptr(),
-                                                        _stream_handle(r.device))
+        rc = _lib.load().ctc_amd_dedup_multihot_targets(r.data_ptr(), B, S, C, int(bool(exact_rows)), out.data_ptr(),
+                                                        length.data_ptr(), _stream_handle(r.device))
     if rc:
         _lib.check(rc, "ctc_amd_dedup_multihot_targets")
     return out, length

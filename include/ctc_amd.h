@@ -30,10 +30,12 @@
 extern "C" {
 #endif
 
-#define CTC_AMD_ABI_VERSION 1
+#define CTC_AMD_ABI_VERSION 2
 
 #define CTC_AMD_ERR_BAD_ARGUMENT      (-1)  /* null pointer, non-positive size ... */
 #define CTC_AMD_ERR_UNSUPPORTED_SHAPE (-2)  /* S > 256 (255 for blank-CTC); binary: T*S beyond LDS */
+#define CTC_AMD_ERR_CODE_OVERFLOW     (-3)  /* target dedup in the reference's int32 row codes with C > 64: the
+                                             * reference raises OverflowError there (2**o at o >= 64) */
 
 /* variants for ctc_amd_workspace_bytes */
 #define CTC_AMD_NOBLANK 0
@@ -57,7 +59,13 @@ size_t ctc_amd_workspace_bytes(int variant, int T, int B, int C, int S);
  *   in_len   [B] int64, 1 <= T_b <= T        tgt_len [B] int64, 1 <= L_b <= S
  *   nll      [B]  out: -alpha[T_b-1, L_b-1]  (1e13 when no alignment exists)
  *   loss     [1]  out: loss_scale * sum_b nll[b]   (loss_scale = 1/B for the
- *            reference's batch mean :139-140; 1/B_global on a batch shard)
+ *            reference's batch mean :139-140; 1/B_global on a batch shard).  The sum is taken
+ *            in-launch in FIXED POINT (order-independent, bitwise reproducible): every nll is
+ *            rounded to a multiple of 2^-F, F = 27 - ceil(log2 B) fractional bits (B = 256: 2^-19,
+ *            i.e. the loss is within 2^-20 of the exactly rounded mean; the reference's
+ *            torch.mean is an fp32 sum in batch order).  nll[] itself and the gradient are
+ *            not quantised.  Values that do not fit (>= 8192, the 1e13 sentinel, NaN) are
+ *            added from memory in double.
  *   grad     [T,B,C] contiguous out, or NULL for a forward-only call:
  *            grad_scale * (softmax(x)[t,b,c] - sum_{l<L_b, lab[b,l]=c} gamma_t(l)),
  *            exactly 0 for t >= T_b and for samples with no alignment
@@ -104,7 +112,8 @@ int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_t stride_b,
  *   nll   [B]  out: un-normalised negative log-likelihood (+inf if infeasible)
  *   loss  [1]  out: loss_scale * sum_b nll[b] / max(L_b,1)
  *   grad  [T,B,C] out or NULL: (exp(lp) - occupancy) * grad_scale / max(L_b,1)
- * Long sequences on batches of #CUs/8..#CUs/4 samples (BASELINE config 5) run as ONE persistent
+ * Long sequences (T >= 256) on batches of #CUs/11..#CUs/2 samples with >= 4 lattice states per lane and
+ * B*C >= 16384 (BASELINE config 5 and its neighbourhood) run as ONE persistent
  * launch of at most one workgroup per CU in which workgroups wait for each other (bounded: a wait
  * that runs out poisons nll / grad with NaN instead of hanging).  Kernels of other streams on the
  * same device can only delay it; the workspace belongs to one call in flight at a time, as for every
@@ -152,11 +161,18 @@ int ctc_amd_noblank_best_path(const float *x, int64_t stride_t, int64_t stride_b
                               void *workspace, void *stream);
 
 /* Target construction: the dedup step of the reference's dataset preparation,
- * datasets/charades_ctc_next_pred.py:653-682 -- out[b] = the distinct non-empty multi-hot rows of rows[b] in
- * order of first appearance, remaining rows filled with -1 (:676-678); length[b] = how many.  rows, out:
- * [B,S,C] int32 (entries 0 / 1); length [B] int64.  Bit-exact integer work; no workspace. */
-int ctc_amd_dedup_multihot_targets(const int32_t *rows, int B, int S, int C, int32_t *out, int64_t *length,
-                                   void *stream);
+ * datasets/charades_ctc_next_pred.py:646-651,663-678 (same code at :503-505,523-531) -- out[b] = the rows of
+ * rows[b] whose code is new, in order of first appearance, remaining rows filled with -1 (:676-678);
+ * length[b] = how many.  rows, out: [B,S,C] int32; length [B] int64.  No workspace.
+ *   exact_rows = 0 (the reference's arithmetic, bit-exact at every C <= 64): rows are compared through the
+ *     int32 code  sum_o row[o] * 2**o  as torch accumulates it into an IntTensor -- wrapped to 32 bits, so
+ *     class 31 is the sign bit and classes 32..63 drop out (opts.py:60-61 default to 38 / 33 classes: rows
+ *     that differ only there collide, rows made only of them never enter); a row enters when its code is
+ *     not among the kept codes, an array that starts as zeros (code 0 never enters).  C > 64 returns
+ *     CTC_AMD_ERR_CODE_OVERFLOW: the reference raises OverflowError at 2**64.
+ *   exact_rows = 1: rows compared exactly over all C classes (which classes are non-zero), any C. */
+int ctc_amd_dedup_multihot_targets(const int32_t *rows, int B, int S, int C, int exact_rows,
+                                   int32_t *out, int64_t *length, void *stream);
 
 /* Per-step posteriors of the no-blank lattice: gamma[b,t,l] = P(state l at step
  * t | x, targets) = exp(alpha_t(l) + beta_t(l) + nll), the quantity the loss gradient scatters

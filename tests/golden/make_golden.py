@@ -202,10 +202,86 @@ def F5(NB, NBB):
              loss=np.float32(loss.item()), nll=nll.numpy(), grad=lp.grad.numpy())
 
 
+def reference_dedup_ops(rows_b):
+    """One clip through the tensor operations of datasets/charades_ctc_next_pred.py:646-651 (row code) and
+    :654-678 (walk, -1 padding), typed here on a given [S, C] block of label rows: the dataset file itself
+    cannot be imported (torchvision, the Charades corpus), and the dedup sits in the middle of a 400-line
+    method.  IntTensor codes, Python `2**o`, `not in` -- whatever this torch does with them is the answer."""
+    S, C = rows_b.shape
+    o_target = torch.tensor(rows_b, dtype=torch.int32)
+    o_target_10 = torch.IntTensor(S).zero_()
+    for t in range(S):
+        for o in range(C):
+            o_target_10[t] += o_target[t, o] * 2 ** o
+    o_only_target = torch.IntTensor(S, C).zero_()
+    o_only_target_10 = torch.IntTensor(S).zero_()
+    o_target_length = 0
+    for t in range(S):
+        if o_target_10[t] not in o_only_target_10:
+            o_only_target_10[t] = o_target_10[t]
+            o_only_target[o_target_length] = o_target[t]
+            o_target_length += 1
+    if o_target_length < S:
+        for pad in range(S - o_target_length):
+            o_only_target[o_target_length + pad] = -1
+    return o_only_target.numpy().copy(), o_target_length
+
+
+def dedup_cases(C, S=10, seed=11):
+    """[B, S, C] int32 label rows exercising the int32 row code at class count C."""
+    rng = np.random.default_rng(seed + C)
+    B = 7
+    rows = np.zeros((B, S, C), np.int32)
+    rows[0] = rng.random((S, C)) < 0.15
+    rows[0, 5] = rows[0, 1]                                   # a repeat that is not adjacent
+    rows[0, 3] = 0                                            # an empty row in the middle
+
+    def hot(b, t, *cls):
+        for c in cls:
+            if c < C:
+                rows[b, t, c] = 1
+    hot(1, 0, 1, 33); hot(1, 1, 1, 35); hot(1, 2, 36); hot(1, 3, 2); hot(1, 4, 1)       # differ only at >= 32
+    hot(2, 0, 32); hot(2, 1, 33, 37); hot(2, 2, 63); hot(2, 4, 0, 63)                    # only classes >= 32
+    hot(3, 0, 31); hot(3, 1, 31, 0); hot(3, 2, 30); hot(3, 3, 31, 32); hot(3, 4, 30, 31)  # the sign bit
+    rows[5, 0, 0] = 2; rows[5, 1, 1] = 1                      # values other than 0 / 1: 2 * 2**0 == 1 * 2**1
+    if C > 30:
+        rows[5, 2, 30] = 2                                    # 2 * 2**30 wraps to the sign bit ...
+        hot(5, 3, 31)                                         # ... which is what class 31 codes to
+        rows[5, 4, 30] = 4                                    # 4 * 2**30 wraps to 0: never enters
+    rows[5, 5, 0] = -1                                        # a negative entry (the -1 padding fed back in)
+    rows[6] = rng.random((S, C)) < 0.5                        # dense rows
+    rows[6, 7:] = rows[6, :3]
+    return rows                                               # rows[4] stays empty: a clip without any label
+
+
+def F6(NB, NBB):
+    """target dedup at class counts around the int32 wrap, the reference's defaults (38 object /
+    33 verb classes, opts.py:60-61) included."""
+    arrs = {"torch_version": np.array(torch.__version__)}
+    for C in (5, 30, 31, 32, 33, 38, 64):
+        rows = dedup_cases(C)
+        out = np.zeros_like(rows)
+        length = np.zeros(rows.shape[0], np.int64)
+        for b in range(rows.shape[0]):
+            out[b], length[b] = reference_dedup_ops(rows[b])
+        arrs["rows_%d" % C], arrs["out_%d" % C], arrs["len_%d" % C] = rows, out, length
+        print("  C=%d lengths %s" % (C, length.tolist()))
+    try:
+        reference_dedup_ops(np.zeros((2, 65), np.int32))
+        arrs["overflow_at_65"] = np.array(0)
+    except OverflowError as e:
+        print("  C=65: OverflowError(%s)" % e)
+        arrs["overflow_at_65"] = np.array(1)
+    save("dedup_targets", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["F6"]:                                # needs torch only, not the reference's modules
+        F6(None, None)
+        sys.exit(0)
     NB, NBB = _import_reference()
-    which = sys.argv[1:] or ["F1", "F2", "F3", "F4", "F5"]
+    which = sys.argv[1:] or ["F1", "F2", "F3", "F4", "F5", "F6"]
     for w in which:
         print(w)
         globals()[w](NB, NBB)

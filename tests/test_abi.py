@@ -34,7 +34,7 @@ def test_binding_covers_header(built):
     from ctc_amd import _lib
     assert sorted(_lib.PROTOTYPES) == _declared()
     lib = _lib.load()
-    assert lib.ctc_amd_abi_version() == 1
+    assert lib.ctc_amd_abi_version() == _lib.ABI_VERSION == 2
     assert lib.ctc_amd_workspace_bytes(0, 150, 256, 158, 20) >= 256
     assert lib.ctc_amd_workspace_bytes(2, 2000, 64, 1000, 100) >= 2 * 64 * 2000 * 201 * 4
     assert b"success" in lib.ctc_amd_error_string(0)

@@ -123,31 +123,72 @@ def test_label_smoothing_restatement_gradient():
     assert np.abs(r["grad"][6:, 1]).max() == 0.0                # rows beyond T_b
 
 
-def test_dedup_targets_restatement_matches_the_reference_algorithm_in_torch():
-    """charades_ctc_next_pred.py:653-682 re-typed with the reference's own tensor operations (IntTensor codes,
-    `not in`) on shapes where int32 codes cannot overflow (C <= 30): pins the numpy restatement."""
+def _reference_dedup_ops(rows_b):
+    """charades_ctc_next_pred.py:646-651,654-678 typed with the reference's own tensor operations (IntTensor
+    codes, Python 2**o, `not in`) -- the same typing tests/golden/make_golden.py F6 captured the fixture with."""
     import torch
-    rng = np.random.default_rng(5)
-    for S, C in ((6, 5), (12, 9), (20, 30)):
-        rows = (rng.random((4, S, C)) < 0.15).astype(np.int32)
-        rows[0, 3] = rows[0, 1]                               # a repeat that is not adjacent
-        rows[1, 2] = 0                                        # an empty row in the middle
-        rows[2] = rows[2, :1]                                 # one distinct row only
-        rows[3] = 0                                           # nothing at all
-        got, length = ctc_numpy.dedup_multihot_targets(rows)
-        for b in range(4):
-            tgt = torch.tensor(rows[b], dtype=torch.int32)
-            code = torch.IntTensor(S).zero_()
-            for t in range(S):
-                for o in range(C):
-                    code[t] += tgt[t, o] * 2 ** o
-            only, only_code, n = torch.IntTensor(S, C).zero_(), torch.IntTensor(S).zero_(), 0
-            for t in range(S):
-                if code[t] not in only_code:
-                    only_code[t] = code[t]
-                    only[n] = tgt[t]
-                    n += 1
-            for pad in range(S - n):
-                only[n + pad] = -1
-            assert n == int(length[b]) and (only.numpy() == got[b]).all()
+    S, C = rows_b.shape
+    tgt = torch.tensor(rows_b, dtype=torch.int32)
+    code = torch.IntTensor(S).zero_()
+    for t in range(S):
+        for o in range(C):
+            code[t] += tgt[t, o] * 2 ** o
+    only, only_code, n = torch.IntTensor(S, C).zero_(), torch.IntTensor(S).zero_(), 0
+    for t in range(S):
+        if code[t] not in only_code:
+            only_code[t] = code[t]
+            only[n] = tgt[t]
+            n += 1
+    for pad in range(S - n):
+        only[n + pad] = -1
+    return only.numpy(), n
+
+
+@pytest.mark.parametrize("S,C", [(6, 5), (12, 9), (20, 30), (8, 31), (8, 32), (8, 33), (10, 38), (6, 64)])
+def test_dedup_targets_restatement_matches_the_reference_algorithm_in_torch(S, C):
+    """Pins the numpy restatement on the reference's tensor operations at every class count up to 64, the
+    reference's defaults (opts.py:60-61: 38 / 33) included: int32 codes wrap -- class 31 is the sign bit,
+    classes >= 32 drop out, code 0 never enters."""
+    rng = np.random.default_rng(5 + C)
+    rows = (rng.random((6, S, C)) < 0.15).astype(np.int32)
+    rows[0, 3] = rows[0, 1]                               # a repeat that is not adjacent
+    rows[1, 2] = 0                                        # an empty row in the middle
+    rows[2] = rows[2, :1]                                 # one distinct row only
+    rows[3] = 0                                           # nothing at all
+    if C > 33:
+        rows[4] = 0
+        rows[4, 0, [1, 33]] = 1                           # rows that differ only in classes >= 32 ...
+        rows[4, 1, [1, C - 1]] = 1
+        rows[4, 2, C - 2] = 1                             # ... and rows made only of them
+        rows[4, 3, 2] = 1
+    rows[5, :, min(31, C - 1)] = 1                        # the sign bit (C >= 32) in every row
+    got, length = ctc_numpy.dedup_multihot_targets(rows)
+    for b in range(6):
+        only, n = _reference_dedup_ops(rows[b])
+        assert n == int(length[b]) and (only == got[b]).all(), (b, n, int(length[b]))
     assert int(length[3]) == 0 and int(length[2]) <= 1
+    if C > 33:
+        assert int(length[4]) == 2                        # {1,33} and {2}: the reference's own answer at C = 38
+
+
+def test_dedup_targets_golden(golden):
+    """the fixture make_golden.py F6 captured from the reference's tensor operations (torch version inside)"""
+    f = golden("dedup_targets")
+    assert int(f["overflow_at_65"]) == 1
+    for C in (5, 30, 31, 32, 33, 38, 64):
+        got, length = ctc_numpy.dedup_multihot_targets(f["rows_%d" % C])
+        assert (length == f["len_%d" % C]).all() and (got == f["out_%d" % C]).all(), C
+    assert f["len_38"].tolist()[1] == 2                   # rows {1,33}, {1,35}, {36}, {2}, {1} -> {1,33}, {2}
+    # exact-row comparison (not the reference) keeps what the int32 code merges
+    _, exact = ctc_numpy.dedup_multihot_targets(f["rows_38"], exact_rows=True)
+    assert int(exact[1]) == 5 and int(exact[2]) == 3
+
+
+def test_dedup_targets_more_than_64_classes_raise_like_the_reference():
+    rows = np.zeros((1, 3, 65), np.int32)
+    with pytest.raises(OverflowError):
+        _reference_dedup_ops(rows[0])
+    with pytest.raises(OverflowError):
+        ctc_numpy.dedup_multihot_targets(rows)
+    out, n = ctc_numpy.dedup_multihot_targets(rows, exact_rows=True)
+    assert int(n[0]) == 0

@@ -848,11 +848,18 @@ def test_noblank_label_smoothing_unsupported_shapes_raise(dev):
 
 
 # ------------------------------------------------------------------ target construction
-@pytest.mark.parametrize("shape", [(1, 1, 1), (4, 6, 5), (9, 20, 33), (16, 150, 158), (3, 70, 300), (5, 200, 38)])
-def test_dedup_multihot_targets_bit_exact(dev, shape):
-    """integer work: bit-exact against the numpy restatement of charades_ctc_next_pred.py:653-682"""
+@pytest.mark.parametrize("shape", [(1, 1, 1), (4, 6, 5), (9, 20, 33), (16, 150, 158), (3, 70, 300), (5, 200, 38),
+                                   (6, 10, 38), (4, 10, 31), (4, 10, 32), (3, 12, 64)])
+@pytest.mark.parametrize("exact", [False, True])
+def test_dedup_multihot_targets_bit_exact(dev, shape, exact):
+    """integer work: bit-exact against the numpy restatement of charades_ctc_next_pred.py:646-651,663-678 --
+    the reference's int32 row codes by default (C <= 64), whole rows with exact_rows"""
     import ctc_amd
     B, S, C = shape
+    if C > 64 and not exact:
+        with pytest.raises(OverflowError):                    # the reference's 2**o raises at o = 64
+            ctc_amd.dedup_multihot_targets(torch.zeros(shape, dtype=torch.int32, device=dev))
+        return
     rng = np.random.default_rng(B * 1000 + S)
     base = (rng.random((B, max(1, S // 3), C)) < 0.1).astype(np.int32)
     pick = rng.integers(0, base.shape[1], (B, S))             # many repeats, adjacent and not
@@ -860,11 +867,71 @@ def test_dedup_multihot_targets_bit_exact(dev, shape):
     rows[0, S // 2] = 0                                       # an empty row
     if B > 1:
         rows[1] = 0                                           # a clip without any label
-    ref, ref_len = ctc_numpy.dedup_multihot_targets(rows)
-    out, length = ctc_amd.dedup_multihot_targets(torch.tensor(rows).to(dev))
+    if B > 2 and C > 33 and S > 4:
+        rows[2, :5] = 0                                       # rows that differ only in classes >= 32, rows made of them
+        rows[2, 0, [1, 33]] = 1; rows[2, 1, [1, C - 1]] = 1; rows[2, 2, C - 2] = 1; rows[2, 3, 2] = 1; rows[2, 4, 1] = 1
+    ref, ref_len = ctc_numpy.dedup_multihot_targets(rows, exact_rows=exact)
+    out, length = ctc_amd.dedup_multihot_targets(torch.tensor(rows).to(dev), exact_rows=exact)
     torch.cuda.synchronize()
     assert (np_(length) == ref_len).all() and (np_(out) == ref).all()
     # int64 input, same answer; the block feeds the binary loss after the reference's .float()
-    out64, len64 = ctc_amd.dedup_multihot_targets(torch.tensor(rows).long().to(dev))
+    out64, len64 = ctc_amd.dedup_multihot_targets(torch.tensor(rows).long().to(dev), exact_rows=exact)
     assert (np_(out64) == ref).all() and (np_(len64) == ref_len).all()
     assert out.dtype == torch.int32 and length.dtype == torch.int64
+
+
+def test_dedup_multihot_targets_golden(dev, golden):
+    """against the fixture captured from the reference's own tensor operations (make_golden.py F6): the int32
+    code wraps at class 31 and drops classes >= 32 -- at the reference's default 38 classes rows {1,33}, {1,35},
+    {36}, {2}, {1} give TWO targets"""
+    import ctc_amd
+    f = golden("dedup_targets")
+    for C in (5, 30, 31, 32, 33, 38, 64):
+        out, length = ctc_amd.dedup_multihot_targets(torch.tensor(f["rows_%d" % C]).to(dev))
+        assert (np_(length) == f["len_%d" % C]).all() and (np_(out) == f["out_%d" % C]).all(), C
+    out, length = ctc_amd.dedup_multihot_targets(torch.tensor(f["rows_38"]).to(dev))
+    assert int(length[1]) == 2
+    _, exact = ctc_amd.dedup_multihot_targets(torch.tensor(f["rows_38"]).to(dev), exact_rows=True)
+    assert int(exact[1]) == 5
+
+
+# ------------------------------------------------------------------ the returned loss is a tensor of its own
+def test_loss_supports_inplace_arithmetic(dev):
+    """`loss /= accum_steps`, `loss *= w`, `loss += aux` on the returned loss (gradient-accumulation loops around
+    train.py:427-444): autograd refuses in-place arithmetic on a VIEW handed out by a custom Function, so the
+    loss and nll must not be views of one buffer."""
+    import ctc_amd
+    x, lab, Tb, L = synth_noblank(3, 30, 6, 12, 5, var_T=True)
+    ref = ctc_numpy.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    for fn in (lambda a, b, c, d: ctc_amd.CTCLoss.apply(a, b, c, d), lambda a, b, c, d: ctc_amd.NoBlankCTC()(a, b, c, d),
+               lambda a, b, c, d: ctc_amd.noblank_ctc_loss(a, b, c, d)[0]):
+        xd = x.to(dev).requires_grad_(True)
+        loss = fn(xd, lab.to(dev), Tb.to(dev), L.to(dev))
+        assert loss._base is None
+        loss /= 2
+        loss *= 3.0
+        loss += 1.0
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss) - (float(ref["loss"]) * 1.5 + 1.0)) < 1e-4
+        assert np.abs(np_(xd.grad) - 1.5 * ref["grad"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("B", [1, 3, 256])
+def test_batch_sum_resolution_on_tiny_losses(dev, B):
+    """The in-launch batch sum is fixed point with 27 - ceil(log2 B) fractional bits (include/ctc_amd.h): tiny
+    per-sample nll must still come through to within that resolution, not be flushed at 2^-17."""
+    import ctc_amd
+    T, C, S = 6, 8, 2
+    x = torch.full((T, B, C), -6.0)
+    x[:3, :, 1] = 6.0                                         # a forced alignment with margin 12: nll ~ 1e-4
+    x[3:, :, 5] = 6.0
+    lab = torch.tensor([[1, 5]] * B, dtype=torch.int32)
+    Tb, L = torch.full((B,), T), torch.full((B,), S)
+    ref = ctc_numpy.noblank_ctc(np_(x), np_(lab), np_(Tb), np_(L), np.float64)
+    loss, nll = ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), Tb.to(dev), L.to(dev))
+    torch.cuda.synchronize()
+    frac = 27 - int(np.ceil(np.log2(B))) if B > 1 else 27
+    assert 1e-5 < float(ref["loss"]) < 1e-3
+    assert abs(float(loss) - float(np_(nll).astype(np.float64).mean())) <= 2.0 ** -(frac + 1) + 1e-11
+    assert abs(float(loss) - float(ref["loss"])) < 1e-6 * float(ref["loss"]) + 2.0 ** -frac

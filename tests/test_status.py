@@ -39,7 +39,7 @@ SCRIPT = textwrap.dedent("""
 @pytest.mark.gpu
 def test_starved_wait_is_loud():
     from ctc_amd import build
-    so = build.build(extra_flags=("-DCTC_AMD_FAULT_INJECT",), name="fault")
+    so = build.build_fault()              # prebuilt by __graft_entry__.build(); compiled here only if missing / stale
     env = dict(os.environ, CTC_AMD_LIB=so, PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "FAULT-INJECTION-OK" in r.stdout, r.stdout + r.stderr

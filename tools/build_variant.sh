@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 python -m ctc_amd.build > /dev/null
 mkdir -p "$ROOT/ctc_amd/lib/variants"
 OBJ="$ROOT/ctc_amd/lib/variants/$NAME.o"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$ROOT/ctc_amd/csrc/$SRC" -o "$OBJ"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DCTC_AMD_EXPERIMENTS "$@" -c "$ROOT/ctc_amd/csrc/$SRC" -o "$OBJ"
 OTHERS=$(ls "$ROOT"/ctc_amd/lib/obj/*.o | grep -v "/${SRC%.hip}.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ctc_amd/lib/variants/$NAME.so" "$OBJ" $OTHERS
 echo "$ROOT/ctc_amd/lib/variants/$NAME.so"
