@@ -16,10 +16,11 @@ N>1 (launched by torch.distributed.run, one rank per GPU, RCCL):
   --scaling strong BASELINE configs[3]: ONE global batch (--global-batch, default 2048), seeded
                    once and sliced -- rank r owns shard_bounds(B, r, N); N=1 runs all of it.
 Either way the gradient scale is 1/B_global, there is no gradient communication, and the
-per-step loss contributions are summed with ONE all-reduce per step (`--loss-bucket 1`, the
-default for N>1: eager launches, the collective asynchronous behind the step's kernels);
-`--loss-bucket M` amortises one all-reduce over M graph-replayed steps and is reported as
-the secondary figure `bucketed` of the default run.
+loss contributions are summed by RCCL: by default the step losses of one hipGraph replay
+(`--graph-steps`, 50) travel in ONE all-reduce of a 50-vector, issued asynchronously behind the
+replay; `--loss-bucket 1` is one all-reduce per step captured into the graph, reported as the
+secondary figure `per_step_collective` of the default run (on this stack a collective kernel
+node beside the step's kernels costs the graph ~18 us per step).
 
 Prints ONE JSON line on rank 0.
 """
@@ -78,6 +79,14 @@ def parse():
                          "hipGraph that never completes is invisible to torch.distributed's own watchdog")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="with --gpus 1: create a one-rank process group and run the N>1 code path (all-reduce per step)")
+    ap.add_argument("--collective-gate", type=int, default=0, choices=[0, 1],
+                    help="collectives in the hipGraph (--loss-bucket 1): hold each step's all-reduce back (ctc_amd_collective_gate) "
+                         "until the NEXT step's loss launch has filled the chip -- RCCL's kernel cannot share a CU with a loss "
+                         "workgroup.  Off by default: inside a captured graph the cross-stream dependencies cost more than the gate saves")
+    ap.add_argument("--occupant", type=int, default=None,
+                    help="--rehearse-collective: a stand-in for the collective's kernel (a 1-rank all-reduce launches none) -- "
+                         "K workgroups with rcclGenericKernel's footprint resident for --occupant-us (default 2 / 15 us)")
+    ap.add_argument("--occupant-us", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 collective backend: nccl = RCCL over xGMI; gloo only to rehearse the multi-rank "
                          "path on a box with fewer GPUs than ranks (ranks then share devices)")
@@ -285,9 +294,12 @@ def main():
         wl = Workload(variant, Bl, Bg, dev, seed=rank)
     B = wl.B
 
-    # N>1 default: ONE all-reduce per step (BASELINE north_star), eager launches so that the
-    # collective can be issued behind each step; N=1 / explicit buckets: steps replayed from hipGraphs
-    bucket = a.loss_bucket if a.loss_bucket is not None else (1 if coll else None)
+    # N > 1 default: the step losses of one graph replay share ONE all-reduce (an M-vector; `--loss-bucket 1` = one per step,
+    # reported as the secondary figure `per_step_collective`).  Measured on one GPU with stand-in collective kernels
+    # (`--rehearse-collective`): a kernel node on a second stream costs a captured graph ~18 us per
+    # step in cross-stream dependencies, issued from Python it is host-bound at ~40 us, and a collective kernel that is
+    # resident when a B = #CUs loss launch starts takes whole CUs away from it (15 -> 23 us).
+    bucket = a.loss_bucket if a.loss_bucket is not None else (None if not a.rehearse_collective else 1) if coll else None
     per_step_collective = coll and bucket == 1
     # one all-reduce per step INSIDE the hipGraph (asynchronous: it runs on RCCL's stream beside the next step's kernel)
     in_graph = per_step_collective and a.launch == "graph" and a.collective_launch == "graph" and a.backend == "nccl"
@@ -303,19 +315,36 @@ def main():
     wl.step(rings[0].data_ptr(), ws, cur_stream(dev))       # first touch outside any capture
     torch.cuda.synchronize()
 
-    def capture(m, collective=False):
+    side = torch.cuda.Stream(dev)                            # the collectives are ordered behind this stream
+    occ_sink = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def capture(m, collective=False, gate=False, occupant=0):
+        """m steps per graph.  collective: one asynchronous all-reduce per step, issued from a side stream that forks off
+        behind the step's kernels -- optionally behind the collective gate (so that RCCL's kernel is dispatched after the
+        NEXT step's loss launch has filled the chip) and, when rehearsing on one GPU, behind `occupant` stand-in workgroups
+        with the collective kernel's footprint."""
         gs = []
         for r in rings:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                s = cur_stream(dev)
+                main = torch.cuda.current_stream(dev)
+                s = main.cuda_stream
                 works = []
                 for j in range(m):
                     wl.step(r.data_ptr() + 4 * j, ws, s)
                     if collective:
-                        works.append(dist.all_reduce(r[j:j + 1], op=dist.ReduceOp.SUM, async_op=True))
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            if gate and j < m - 1:          # (only when a loss launch follows in this graph: the gate is bounded, not free)
+                                rc = wl.lib.ctc_amd_collective_gate(ws.data_ptr(), wl.B, 30, side.cuda_stream)
+                                assert rc == 0, rc
+                            if occupant:
+                                occ_lib.coresident_launch(occupant, a.occupant_us, occ_sink.data_ptr(), side.cuda_stream)
+                            works.append(dist.all_reduce(r[j:j + 1], op=dist.ReduceOp.SUM, async_op=True))
                 for w in works:                             # (joins RCCL's stream back into the capture)
                     w.wait()
+                if collective:
+                    main.wait_stream(side)
             gs.append(g)
         return gs
 
@@ -324,9 +353,16 @@ def main():
         torch.cuda.synchronize()
         rings[0].zero_()
     graphs = []
+    occ_lib = None
+    n_occ = a.occupant if a.occupant is not None else (2 if (a.rehearse_collective and world == 1) else 0)
+    if n_occ:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import coresident
+        occ_lib = coresident.load_occupant()
+    use_gate = bool(a.collective_gate) and variant != "blank"
     if in_graph:
         try:
-            graphs = capture(M, collective=True)
+            graphs = capture(M, collective=True, gate=use_gate, occupant=n_occ)
             graphs[0].replay()
             torch.cuda.synchronize()
         except Exception as e:                              # noqa: BLE001 -- any failure: the eager path still works
@@ -393,7 +429,21 @@ def main():
     els = sorted(timed(K) for _ in range(repeats))
     el = els[len(els) // 2]
 
-    # secondary figure for N>1: the same steps with the loss all-reduce amortised over a graph replay
+    # secondary figures for N>1: the same steps with the loss all-reduce amortised over a graph replay (`bucketed`, when
+    # the primary run has one all-reduce per step), or with one all-reduce per step captured into the graph
+    # (`per_step_collective`, when the primary run is the bucketed default)
+    per_step = None
+    if coll and not per_step_collective and a.launch == "graph" and a.backend == "nccl" and launch == "graph":
+        try:
+            gp = capture(M, collective=True, gate=use_gate, occupant=0)
+            run_steps(M, launch="graph", graphs=gp, M=M, bucket=1, graph_collective=True)
+            npst = max(M, min(K, 200) // M * M)
+            elp = timed(npst, launch="graph", graphs=gp, M=M, bucket=1, graph_collective=True)
+            per_step = {"value": round(B_total(world, wl, a) * npst / elp, 1), "unit": "samples/s", "steps": npst,
+                        "ms_per_step": round(elp / npst * 1e3, 6), "launch": "graph", "graph_steps": M,
+                        "loss_allreduce_bucket": 1, "collective_launch": "in the hipGraph, one asynchronous all-reduce per step"}
+        except Exception as e:                              # noqa: BLE001
+            per_step = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     bucketed = None
     if per_step_collective and a.launch == "graph":
         Mb = max(1, min(a.graph_steps, K))
@@ -404,6 +454,21 @@ def main():
         bucketed = {"value": round(B_total(world, wl, a) * nb / elb, 1), "unit": "samples/s", "steps": nb,
                     "ms_per_step": round(elb / nb * 1e3, 6), "launch": "graph", "graph_steps": Mb,
                     "loss_allreduce_bucket": Mb}
+
+    # rehearsal on one GPU: the same graph with the stand-in collective kernel, gated and not, and without a collective
+    coresident = None
+    if in_graph and n_occ and world == 1:
+        coresident = {"occupant": "%d workgroups with rcclGenericKernel's footprint (256 threads, 19744 B LDS, 280 registers "
+                                  "per lane), resident %.0f us, where each step's all-reduce kernel would run" % (n_occ, a.occupant_us)}
+        for label, kw in (("gated_us_per_step", dict(collective=True, gate=True, occupant=n_occ)),
+                          ("ungated_us_per_step", dict(collective=True, gate=False, occupant=n_occ)),
+                          ("allreduce_only_us_per_step", dict(collective=True, gate=False, occupant=0)),
+                          ("no_collective_us_per_step", dict(collective=False))):
+            gx = capture(M, **kw)
+            nb = max(M, K // M * M)
+            run_steps(M, launch="graph", graphs=gx, M=M, bucket=M, graph_collective=True)
+            elx = sorted(timed(nb, launch="graph", graphs=gx, M=M, bucket=M, graph_collective=True) for _ in range(3))[1]
+            coresident[label] = round(elx / nb * 1e6, 3)
 
     # ---- dominant kernel: per-launch duration from HIP events on the launch stream
     n_ev = 200 if variant != "blank" else 20
@@ -470,6 +535,12 @@ def main():
         }
         if bucketed is not None:
             out["bucketed"] = bucketed
+        if per_step is not None:
+            out["per_step_collective"] = per_step
+        if coresident is not None:
+            out["coresident"] = coresident
+        if coll:
+            out["config"]["collective_gate"] = bool(use_gate and in_graph)
         # (before anything multi-threaded runs on the host: the checker's OpenMP workers keep spinning for a while after
         # their last parallel region and the autograd engine's thread wake-ups then take 2-3x as long)
         eager = eager_python_step(wl, 300 if variant != "blank" else 20) if (world == 1 and not a.no_eager_python) else None

@@ -51,3 +51,25 @@ extern "C" int ctc_amd_workspace_status(void *workspace, int clear, void *stream
     if (e == hipSuccess && clear && *status_host != 0) e = hipMemsetAsync(word, 0, sizeof(unsigned), s);
     return (int)e;
 }
+
+// ---- collective gate (include/ctc_amd.h) ---------------------------------------------
+namespace ctc {
+__global__ __launch_bounds__(64) void collective_gate_kernel(const unsigned *counter, unsigned need, unsigned long long ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+    while (__hip_atomic_load(counter + kArrivalsWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need &&
+           __builtin_amdgcn_s_memrealtime() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace ctc
+
+extern "C" int ctc_amd_collective_gate(void *workspace, int B, int timeout_us, void *stream)
+{
+    if (!workspace || B < 1 || timeout_us < 0) return CTC_AMD_ERR_BAD_ARGUMENT;
+    const int cus = ctc::device_cus();
+    const unsigned need = (unsigned)(cus > 0 && B > cus ? cus : B);       // one round of workgroups fills the chip
+    hipLaunchKernelGGL(ctc::collective_gate_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned *>(workspace), need, (unsigned long long)timeout_us * 100ull);
+    return (int)hipGetLastError();
+}

@@ -10,7 +10,8 @@
 #if !defined(CTC_AMD_EXPERIMENTS) &&                                                                            \
     (defined(CTC_X_NOSTATUS) || defined(CTC_X_NOREDUCE) || defined(CTC_X_NORETURN) || defined(CTC_X_NOCHAIN) || \
      defined(CTC_X_NOPRIO) || defined(CTC_X_NOREAD) || defined(CTC_X_NOWRITE) || defined(CTC_X_FULL_LATTICE) || \
-     defined(CTC_X_GATHER_ONCE))
+     defined(CTC_X_GATHER_ONCE) || defined(CTC_X_WMASK) || defined(CTC_X_NOPROG) || defined(CTC_X_NORENORM) || \
+     defined(CTC_X_ROWDPP))
 #error "CTC_X_* experiment switches need -DCTC_AMD_EXPERIMENTS (A/B builds only, never the product library)"
 #endif
 
@@ -78,6 +79,18 @@ __device__ __forceinline__ void raise_status(unsigned *counter, unsigned bit)
     return;
 #endif
     if (lane_id() == 0) __hip_atomic_fetch_or(counter + 2, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Workspace word 10 (bytes [40,44)): ARRIVALS -- how many workgroups of the launch in flight have started.  One
+// no-return atomic per workgroup at entry, issued by a wave that has no other vector-memory operation to wait
+// for (a chain / scan wave); the workgroup that completes the batch sum (the last to finish, so every workgroup
+// has arrived) puts the word back to 0.  Read by ctc_amd_collective_gate (api.hip): a collective that would
+// otherwise be dispatched BEFORE this launch and take whole CUs away from it is held
+// back until the launch has filled the chip.
+constexpr int kArrivalsWord = 10;
+__device__ __forceinline__ void note_arrival(unsigned *counter)
+{
+    __hip_atomic_fetch_add(counter + kArrivalsWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Diagnostics (phase stamps, early exits) compile to nothing in the product library.
@@ -335,6 +348,7 @@ __device__ __forceinline__ void ticket_and_reduce(int B, float *nll, float *loss
     if (lane_id() == 0) {
         loss[0] = s * loss_scale;
         __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(counter + kArrivalsWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 template <typename F>
@@ -415,6 +429,7 @@ __device__ __forceinline__ void publish_and_reduce_sum(float value, int b, int B
         s += (double)__hip_atomic_load(&nll[bb < (unsigned)B ? bb : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     loss[0] = (float)(s * (double)loss_scale);
+    __hip_atomic_store(counter + kArrivalsWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(top, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(nlist, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
 {
     extern __shared__ float4 smem_raw[];
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id();
+    if (tid == kThreads - 64) note_arrival(p.counter);       // (the last wave: its first wait is the workgroup barrier)
     const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C,
                          GLB ? p.lattice + (int64_t)b * p.slab : nullptr);
     constexpr int CHR = CH > 0 ? CH : 1;
@@ -619,7 +620,8 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
 // Diagnostic entry point (tools/chain_probe.py), not part of include/ctc_amd.h: the lattice chains of
 // noblank_r16.hpp alone, every emission row pre-published; out[0], out[1] = shader cycles of the
 // alpha / beta chain.
-extern "C" int ctc_amd_debug_chain_probe(int T, int SP, int waves_alive, int grid, void *out, void *stream)
+extern "C" int ctc_amd_debug_chain_probe(int T, int SP, int waves_alive, int grid, void *out, void *stream, int mode,
+                                         int chain_b)
 {
     using namespace ctc;
     NoblankParams p = {};
@@ -628,6 +630,6 @@ extern "C" int ctc_amd_debug_chain_probe(int T, int SP, int waves_alive, int gri
     p.counter = reinterpret_cast<unsigned *>(static_cast<unsigned long long *>(out) + 8);
     const size_t smem = r16_smem_bytes(T, SP, 158);
     return launch<r16_chain_probe_kernel>(dim3(grid), dim3(kThreads), smem, static_cast<hipStream_t>(stream), p,
-                                          static_cast<unsigned long long *>(out), waves_alive);
+                                          static_cast<unsigned long long *>(out), waves_alive, mode, chain_b);
 }
 #endif

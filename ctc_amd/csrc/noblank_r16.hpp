@@ -184,8 +184,13 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
             "v_ldexp_f32 %[d2], " EM ", %[d2]\n\t"                                                    \
             "v_mul_f32 " T2 ", " M ", %[d1]\n\t"                                                      \
             "v_fmac_f32_dpp " T2 ", " M ", %[d2] " DPP "\n\t"
+#ifdef CTC_X_ROWDPP                                           // experiment: what the cross-row shift costs (wrong beyond 16 states)
+#define CTC_R16_DPP_F "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define CTC_R16_DPP_B "row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#else
 #define CTC_R16_DPP_F "wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #define CTC_R16_DPP_B "wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#endif
     auto step = [&](float em_, float ek_) {                  // a single step (alignment peel)
         int kk, k2, d1, d2;
         float t;
@@ -270,10 +275,14 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
     const unsigned long long loop_t0 = CTC_DIAG(p) == -77 ? __builtin_amdgcn_s_memtime() : 0;   // (chain probe only)
     for (; i + kR16Block <= Tb; i += kR16Block) {
         lds_order();
+#ifndef CTC_X_NOPROG
         *prog = i;                                           // steps < i are done (every lane, same value)
+#endif
         if (have < G) wait_upto(i + kR16Block - 1 + kPrefetch);
         if (CTC_DIAG(p) < 0) stamp(p, 2 + i / 16);       // diagnostic: block starts -> slots 2..10
+#ifndef CTC_X_NORENORM
         renorm();
+#endif
 #pragma unroll
         for (int q = 0; q < kPairs; ++q) {
             const pair_t e = ring[q & 1];
@@ -283,6 +292,9 @@ __device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Sme
 #ifdef CTC_X_NOWRITE
             const pair_t o = step2(e, q == 0);
             if (q == kPairs - 1) wb[0] = o;
+#elif defined(CTC_X_WMASK)
+            const pair_t o = step2(e, q == 0);
+            if (lane < SP) wb[FWD ? q : kPairs - 1 - q] = o;  // experiment: idle lanes switched off for the store
 #else
             wb[FWD ? q : kPairs - 1 - q] = step2(e, q == 0);
 #endif
@@ -476,6 +488,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     constexpr int G = kPipeRows / 4;                         // groups of four rows per worker
     const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, RP);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    if (tid == 64 * kChainB) note_arrival(p.counter);        // (the beta chain wave has no other vector-memory operation)
     const int u = (w == 0 || w == kChainB) ? -1 : (w < kChainB ? w - 1 : w - 2);
     const int rho = lane >> 4, i16 = lane & 15;              // row of the group, position inside the row
     const float ninf = -__builtin_inff();
@@ -776,27 +789,65 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 // ---- diagnostic probe (tools/chain_probe.py): the chains alone, every row already published ------
 // (diagnostics build only: the product library carries no kernel it never launches)
 #ifdef CTC_AMD_DIAGNOSTICS
-__global__ __launch_bounds__(kThreads, 4) void r16_chain_probe_kernel(NoblankParams p, unsigned long long *out, int waves_alive)
+// `mode`: what the other waves do while the chains run -- 0: poll the chain's progress and sleep (a waiting
+// worker); 1: VALU only (fma + one exp in eight, like a worker's P1 / P3 arithmetic); 2: LDS only (16-byte tile
+// writes and 8-byte cell reads in the wave's own staging tile); 3: both, in a worker's proportions (150 : 10);
+// +8: at wave priority 2 (a worker's first group).  The chains are waves 0 and `chain_b`.
+__global__ __launch_bounds__(kThreads, 4) void r16_chain_probe_kernel(NoblankParams p, unsigned long long *out, int waves_alive,
+                                                                     int mode, int chain_b)
 {
     extern __shared__ float4 smem_raw[];
-    const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, 32);
+    const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, 160);
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
     for (int i = tid; i < 3 * (p.SP + 1) * sm.TP; i += kThreads) sm.em[i - kR16Pad] = make_cell(1.5f, -1);
     if (tid < 16) sm.cnt[tid] = kPipeRows;                   // everything published
     __syncthreads();
-    if (w >= waves_alive) return;
-    if (w > 1) {                                             // bystanders: poll like a waiting worker
+    if (w >= waves_alive && w != chain_b) return;
+    if (w != 0 && w != chain_b) {                            // bystanders
         typedef const volatile __attribute__((address_space(3))) int lds_cvint;
         int spins = 0;
-        while (*(lds_cvint *)(sm.cnt + kPipeWorkers) < p.T && ++spins < 100000) __builtin_amdgcn_s_sleep(8);
+        const int u = (w < chain_b ? w - 1 : w - 2) % kPipeWorkers;
+        float *tile = sm.stage + (size_t)u * 4 * 160 + (lane >> 4) * 160 + 4 * (lane & 15);
+        const cell_t *cells = sm.al + (size_t)(lane & 15) * sm.TP;
+        if (mode & 8) __builtin_amdgcn_s_setprio(2);
+        float a0 = lane, a1 = 1.f, a2 = 2.f, a3 = 3.f, acc = 0.f;
+        const int kind = mode & 7;
+        while (*(lds_cvint *)(sm.cnt + kPipeWorkers) < p.T && ++spins < 100000) {
+            if (kind == 0) { __builtin_amdgcn_s_sleep(8); continue; }
+            if (kind & 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {               // 16 x (7 fma + 1 exp) = 128 VALU
+                    a0 = __builtin_fmaf(a0, 1.0001f, a1); a1 = __builtin_fmaf(a1, 0.9999f, a2);
+                    a2 = __builtin_fmaf(a2, 1.0001f, a3); a3 = __builtin_fmaf(a3, 0.9999f, a0);
+                    a0 = __builtin_fmaf(a0, 0.5f, a2); a1 = __builtin_fmaf(a1, 0.5f, a3);
+                    a2 = __builtin_fmaf(a2, 0.5f, 1.f);
+                    a3 = __builtin_amdgcn_exp2f(a3 * 1e-3f);
+                }
+            }
+            if (kind & 2) {
+                const int reps = kind == 2 ? 12 : 1;
+                for (int r = 0; r < reps; ++r) {             // per 128 VALU: 3 x 16-byte + 2 x 16-byte tile traffic, 6 cell reads
+                    f4_t v4 = {a0, a1, a2, a3};
+                    *reinterpret_cast<f4_t *>(tile) = v4;
+                    *reinterpret_cast<f4_t *>(tile + 64) = v4;
+                    *reinterpret_cast<f2_t *>(tile + 128) = f2_t{a0, a1};
+                    lds_order();
+                    const f4_t r4 = *reinterpret_cast<const f4_t *>(tile + 64);
+                    const cell_t c0 = cells[8 + (spins & 63)], c1 = cells[sm.TP * 16 + 9 + (spins & 63)];
+                    acc += r4.x + c0.x + c1.x;
+                    lds_order();
+                }
+            }
+        }
+        if (acc + a0 + a1 + a2 + a3 == 12345.f) out[15] = 1;  // (keeps the loop alive)
         return;
     }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const cell_t c = w == 0 ? r16_chain<true>(p, sm, p.T, p.T, p.SP, p.SP) : r16_chain<false>(p, sm, p.T, p.T, p.SP, p.SP);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (lane == 0 && blockIdx.x == 0) {
-        out[w] = t1 - t0;
-        out[4 + w] = (unsigned long long)cell_k(c);
+        out[w == 0 ? 0 : 1] = t1 - t0;
+        out[4 + (w == 0 ? 0 : 1)] = (unsigned long long)cell_k(c);
     }
 }
 #endif  // CTC_AMD_DIAGNOSTICS

@@ -91,6 +91,26 @@ def check_status(device=None):
                                "carry NaN -- see include/ctc_amd.h, ctc_amd_workspace_status" % (what, st))
 
 
+def collective_gate(variant, batch, device=None, launch_stream=None, timeout_us=30):
+    """Enqueue, on the CURRENT stream, a one-wave kernel that returns once the next no-blank / binary loss launch
+    issued on `launch_stream` (default: the stream that is current now ... call this under
+    ``torch.cuda.stream(side)`` with ``launch_stream=main.cuda_stream``) has filled the chip, or after `timeout_us`.
+    Put it between the previous loss launch and an asynchronous collective so that the collective's kernel is
+    not dispatched in front of the next launch (include/ctc_amd.h: ctc_amd_collective_gate).  No-op (returns
+    False) when that stream has not run a loss of this variant yet."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.index, _stream_handle(dev) if launch_stream is None else launch_stream,
+           {"noblank": _lib.NOBLANK, "binary": _lib.BINARY}.get(variant, variant))
+    held = _workspaces.get(key)
+    if not held:
+        return False
+    with _on_device(dev):
+        rc = _lib.load().ctc_amd_collective_gate(held[-1].data_ptr(), int(batch), int(timeout_us), _stream_handle(dev))
+    if rc:
+        _lib.check(rc, "ctc_amd_collective_gate")
+    return True
+
+
 def set_blank_schedule(mode):
     """-1: the library chooses (default); 1 / 0: force / forbid the persistent blank-CTC launch."""
     _lib.check(_lib.load().ctc_amd_blank_set_schedule(int(mode)), "ctc_amd_blank_set_schedule")

@@ -16,7 +16,7 @@
  *  - the caller owns all memory.  `workspace` must hold ctc_amd_workspace_bytes(...)
  *    bytes, be zero-filled ONCE when allocated, and not be shared by launches that
  *    may run concurrently (one workspace per stream); bytes [8,12) are the status word
- *    (ctc_amd_workspace_status);
+ *    (ctc_amd_workspace_status), bytes [40,44) the arrivals word (ctc_amd_collective_gate);
  *  - return value: 0 on success, a hipError_t (> 0) from the launch, or one of the
  *    negative CTC_AMD_ERR_* codes; ctc_amd_error_string() describes any of them.
  */
@@ -139,6 +139,19 @@ int ctc_amd_blank_set_schedule(int mode);
  * Bits: 1 no-blank, 2 binary, 4 blank-CTC launch starved.  Never observed outside fault-injection builds;
  * the persistent blank-CTC launch is the one place where another process's kernels could cause it. */
 int ctc_amd_workspace_status(void *workspace, int clear, void *stream, unsigned *status_host);
+
+/* Collective gate (batch-sharded use, one process per GPU): keeps a collective from taking CUs away from the
+ * NEXT loss launch.  The no-blank / binary launch at B >= #CUs wants every CU (one 1024-thread workgroup, 122 KB
+ * of LDS, 288 of a SIMD's 512 registers per lane); RCCL's collective kernel (256 threads, 19.7 KB of LDS, 261-280
+ * registers per lane) cannot share a CU with such a workgroup, so an all-reduce that is dispatched just BEFORE
+ * the launch costs it a whole second round of workgroups (measured: 15 -> 23 us per launch with one resident
+ * collective workgroup; dispatched after the launch has filled the chip it costs nothing).  Enqueue this on the
+ * stream the collective will be ordered behind, AFTER the previous loss launch and BEFORE the collective: a
+ * one-wave kernel that returns once min(B, #CUs) workgroups of the loss launch that uses `workspace` have
+ * started (every no-blank / binary workgroup counts itself in workspace word 10 at entry, the launch's last
+ * workgroup puts the word back to 0), or after timeout_us (bounded: never gate a collective that no loss
+ * launch follows).  The blank-CTC launches do not count arrivals (a collective is short against them). */
+int ctc_amd_collective_gate(void *workspace, int B, int timeout_us, void *stream);
 
 /* backward of the autograd.Function: grad[i] *= *grad_out (a device scalar, the
  * upstream gradient of the 0-dim loss).  Every workgroup reads *grad_out and exits

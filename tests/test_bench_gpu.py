@@ -41,6 +41,63 @@ def test_bench_collective_path_rehearsal():
     assert c["collective"] == "nccl" and c["loss_allreduce_bucket"] == 1 and c["launch"] == "graph"
     assert c["collective_launch"].startswith("in the hipGraph")
     assert math.isfinite(d["value"]) and d["value"] > 1e6
+    # A one-rank all-reduce launches no kernel; the rehearsal also puts workgroups with RCCL's kernel footprint where each
+    # step's all-reduce kernel would run (a kernel node on a second stream is what costs a captured
+    # graph its time, which is why real N > 1 runs default to one all-reduce per graph replay).
+    co = d["coresident"]
+    for k in ("gated_us_per_step", "ungated_us_per_step", "allreduce_only_us_per_step", "no_collective_us_per_step"):
+        assert math.isfinite(co[k]) and co[k] > 5.0, co
+    assert abs(co["allreduce_only_us_per_step"] - co["no_collective_us_per_step"]) < 2.0, co
+    assert co["ungated_us_per_step"] > co["no_collective_us_per_step"] + 3.0, co
     e = _bench("--rehearse-collective", "--collective-launch", "eager")
     assert e["config"]["launch"] == "eager" and e["config"]["collective_launch"].startswith("eager")
     assert math.isfinite(e["value"]) and e["value"] > 1e5
+
+
+def test_collective_gate_returns_and_arrivals_word_resets():
+    """ctc_amd_collective_gate: returns at once when nothing needs holding back (B below the chip), within its
+    bound when no loss launch follows, and the launch's last workgroup puts the arrivals word back to 0."""
+    import time
+    import torch
+    import ctc_amd
+    from ctc_amd import functional as F
+    from tests.helpers import synth_noblank
+    dev = torch.device("cuda:0")
+    x, lab, Tb, L = synth_noblank(0, 150, 256, 158, 20)
+    args = (x.to(dev).requires_grad_(True), lab.to(dev), Tb.to(dev), L.to(dev))
+    assert F.collective_gate("noblank", 256, dev, launch_stream=123456789) is False      # no such stream's workspace
+    loss = ctc_amd.CTCLoss.apply(*args)
+    torch.cuda.synchronize()
+    key = (dev.index, F._stream_handle(dev), 0)
+    ws = F._workspaces[key][-1]
+    assert int(ws[40:44].view(torch.int32).item()) == 0                                 # reset by the last workgroup
+    side = torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev)
+    for follow in (True, False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(side):
+            assert F.collective_gate("noblank", 256, dev, launch_stream=main.cuda_stream, timeout_us=20000)
+        if follow:
+            loss = ctc_amd.CTCLoss.apply(*args)                                          # fills the chip: the gate opens
+        side.synchronize()
+        el = time.perf_counter() - t0
+        assert (el < 0.015) if follow else (0.015 < el < 0.2), (follow, el)             # opened by the launch / by its bound
+    torch.cuda.synchronize()
+    assert int(ws[40:44].view(torch.int32).item()) == 0
+    assert ctc_amd.workspace_status() == 0
+
+
+def test_resident_collective_kernel_costs_a_round_unless_the_launch_came_first():
+    """tools/coresident.py: workgroups with RCCL's kernel footprint cannot share a CU with a loss workgroup (280 + 288
+    registers per lane > 512).  Resident BEFORE the B = #CUs launch they cost it a second round of workgroups; enqueued
+    after it, or held back by ctc_amd_collective_gate until the launch has filled the chip, they cost it nothing."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "coresident.py")], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])["us_per_launch_event_bracketed_median"]
+    base = d["loss first"]["k=0"]
+    assert d["collective first"]["k=1"] > base + 4.0, d
+    for order in ("loss first", "gated"):
+        for k in ("k=1", "k=2", "k=8"):
+            assert d[order][k] < base + 1.5, (order, k, d)
