@@ -101,11 +101,36 @@ constexpr bool kGatherOnce = true;
 constexpr bool kGatherOnce = false;
 #endif
 
-// ints of hand-off state behind the per-sample tables (see BlankParams::sync)
+// Persistent launch, float4 rows: the IDLE WORKER POOL gathers the emission rows.  Until the chains cross in the middle
+// of the samples the row workers have nothing to do (38 % of the launch at B=64 T=2000: 192 CUs idle, HBM a third
+// used) while each sample's CU issues every log_probs line request of its six loaders, stages the 4-KB rows in LDS and
+// gathers them -- and its chain still waits 17 % of that phase for emission rows (34 % later, beside the streaming
+// workers: tools/blank_stamps.py, CTC_AMD_BLANK_DEBUG=384).  So the pool does that work first: every log_probs row is
+// read ONCE, in the order in which the chains want it (row t of a sample is wanted at distance min(t, T_b-1-t) from
+// the nearer end: by alpha at step t, by beta at step T_b-1-t), gathered by class into the 4 K bytes per lane the
+// chains consume (log2 units) and left in the workspace (p.em, the three-launch schedule's emission table) with
+// write-through stores; then the pool turns to the gradient as before.  A sample's workgroup keeps two light loader
+// waves per direction (0.8 KB per row instead of 4 KB, no LDS staging, no gather) and one SCOUT wave per direction.
+// Hand-off pool -> sample: rows are counted per (sample, chunk of kPoolChunk distances) with an agent-scope atomic
+// AFTER the gathering wave's stores have landed (s_waitcnt vmcnt(0)); the scout polls the counters in order and
+// publishes "chunks complete" in LDS; a loader issues the load of a row only when its chunk is known complete (the
+// flag is read, and waited for, BEFORE the row is loaded: loads of one wave may be served out of order).  The second
+// half of a chain's steps are rows the other direction needed first: no further checks.  Producers never wait.
+#ifdef CTC_X_NO_POOL_GATHER
+constexpr bool kPoolGather = false;
+#else
+constexpr bool kPoolGather = true;
+#endif
+constexpr int kPoolChunk = 16;       // distances per hand-off counter
+constexpr int kPoolBatch = 4;        // rows a gathering wave keeps in flight
+constexpr int kPoolLoaders = 2;      // data loaders per direction when the pool gathers (the third loader wave is the scout)
+
+__host__ __device__ inline int blank_pool_chunks(int T) { return (((T + 1) >> 1) + kPoolChunk - 1) / kPoolChunk; }
+// ints of hand-off state behind the per-sample tables (see BlankParams::sync): status word, two progress counters
+// per sample (one 128-byte line each), the pool-gather chunk counters [B][chunks]
 int blank_sync_ints(int T, int B)
 {
-    (void)T;
-    return kSyncHead + 2 * ((B + 63) & ~63) * kProgPitch;
+    return kSyncHead + 2 * ((B + 63) & ~63) * kProgPitch + ((B * blank_pool_chunks(T) + 63) & ~63);
 }
 
 struct BlankParams {
@@ -125,7 +150,8 @@ struct BlankParams {
     // fused schedule: sync[0] status, sync[kSyncHead + (dir Bp + b) kProgPitch]
     // steps of chain `dir` of sample b whose lattice rows have landed
     int *sync;
-    int Bp, nsync;
+    int *chunk;                      // [B][nchunk] rows of that chunk of distances gathered by the pool (fused schedule)
+    int Bp, nsync, nchunk;
     int debug;                       // CTC_AMD_BLANK_DEBUG (diagnostics: 128 = timeline stamps)
 };
 
@@ -159,6 +185,20 @@ __device__ __forceinline__ bool lds_wait_ge(const BlankParams &p, const int *fla
     if (!ok) { agent_store(p.sync, 1); raise_status(p.counter, kStatusBlankStarved); }
     asm volatile("" ::: "memory");
     return ok;
+}
+
+// The same wait without any vector-memory operation inside (no look at the global status word, no status raised here):
+// for loops that keep vector loads in flight -- a vector-memory operation on a side path makes the compiler's
+// s_waitcnt bookkeeping assume the worst at the join, and "twelve rows in flight" silently become one.  The caller
+// raises the status when this returns false.
+__device__ __forceinline__ bool lds_wait_ge_quiet(const int *flag, int target, int &seen)
+{
+    for (int it = 0; it < kLdsSpinLimit; ++it) {
+        seen = wg_load(flag);
+        if (seen >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
 }
 
 // diagnostics (CTC_AMD_BLANK_DEBUG & 128): 100-MHz timestamps into workspace bytes [64,256), tools/blank_stamps.py
@@ -602,9 +642,144 @@ __device__ __forceinline__ void blank_loader_rows(const BlankParams &p, int b, i
 // One chain of the fused schedule: emissions from the LDS ring, kGroup steps per hand-off check;
 // lattice rows written through to memory (beta WITHOUT its own emission), and the number of steps
 // whose rows have landed published per group.
-template <int K, bool FWD>
+// ---- pool gather (see kPoolGather) -------------------------------------------------------------------------------
+// rows of chunk c of a sample with T_b frames the pool will gather: distances [c kPoolChunk, min(.., H)), both ends,
+// the middle row of an odd T_b once
+__device__ __forceinline__ int blank_chunk_rows(int Tb, int c)
+{
+    const int H = (Tb + 1) >> 1, lo = c * kPoolChunk, hi = min(lo + kPoolChunk, H);
+    if (hi <= lo) return 0;
+    return 2 * (hi - lo) - (((Tb & 1) && H - 1 >= lo && H - 1 < hi) ? 1 : 0);
+}
+
+// A worker wave's share of the gather: items q = (distance i, sample b, end) in that order of priority, kPoolBatch
+// consecutive items per turn, turns dealt round-robin over the nw worker waves.  Never waits for anybody.
+template <int K>
+__device__ __forceinline__ void blank_pool_gather(const BlankParams &p, int wid, int nw, float *stage)
+{
+    constexpr int NB = kPoolBatch;
+    const int lane = lane_id(), s0 = lane * K, c4 = p.C >> 2;
+    const long long Q = 2ll * p.B * ((p.T + 1) >> 1);
+    for (long long q0 = (long long)wid * NB; q0 < Q; q0 += (long long)nw * NB) {
+        int bq[NB], tq[NB], nq[NB], cq[NB];
+        f4_t x[NB][kMaxV4];
+        i4_t cl[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {                       // (wave-uniform bookkeeping; every item issues the same loads)
+            const long long q = q0 + k;
+            const int i = (int)(q / (2 * p.B)), r = (int)(q - (long long)i * 2 * p.B);
+            const int b = r >> 1, end = r & 1;
+            int Tb, Lb;                                      // (the lengths the sample's own workgroup goes by: a sample
+            blank_sample_ok(p, b, Tb, Lb);                   // without an alignment still runs its chains, to -inf)
+            const int H = (Tb + 1) >> 1;
+            const bool live = q < Q && i < H && !(end == 1 && (Tb & 1) && i == H - 1);
+            bq[k] = __builtin_amdgcn_readfirstlane(b);
+            tq[k] = __builtin_amdgcn_readfirstlane(live ? (end ? Tb - 1 - i : i) : -1);
+            nq[k] = __builtin_amdgcn_readfirstlane(2 * Lb + 1);
+            cq[k] = __builtin_amdgcn_readfirstlane(i / kPoolChunk);
+            const f4_t *row = reinterpret_cast<const f4_t *>(p.lp + (int64_t)(tq[k] >= 0 ? tq[k] : 0) * p.st + (int64_t)bq[k] * p.sb);
+#pragma unroll
+            for (int v = 0; v < kMaxV4; ++v) x[k][v] = row[min(lane + kWave * v, c4 - 1)];   // (past the row: its last float4 again)
+            static_assert(K == 4 || K == 2 || K == 8, "class table read below");
+            if constexpr (K == 4) cl[k] = *reinterpret_cast<const i4_t *>(p.cls + bq[k] * p.NSP + s0);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if (tq[k] < 0) continue;                         // (wave-uniform)
+#pragma unroll
+            for (int v = 0; v < kMaxV4; ++v) reinterpret_cast<f4_t *>(stage)[lane + kWave * v] = x[k][v];
+            asm volatile("" ::: "memory");                   // (same wave: LDS keeps program order)
+            float e[K];
+            if constexpr (K == 4) {
+                const int c0 = cl[k].x, c1 = cl[k].y, c2 = cl[k].z, c3 = cl[k].w;
+                const int cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int j = 0; j < K; ++j) e[j] = s0 + j < nq[k] ? fmaxf(stage[cc[j]] * kLog2e, kNegB) : kNegB;
+            } else {
+#pragma unroll
+                for (int j = 0; j < K; ++j) e[j] = s0 + j < nq[k] ? fmaxf(stage[p.cls[bq[k] * p.NSP + s0 + j]] * kLog2e, kNegB) : kNegB;
+            }
+            asm volatile("" ::: "memory");                   // (the staged row is read before the next one overwrites it)
+            const __amdgpu_buffer_rsrc_t ersrc = lattice_rsrc(p.em + (int64_t)bq[k] * p.T * p.NSP, p.T, p.NSP);
+            agent_store_row<K>(ersrc, tq[k] * p.NSP * (int)sizeof(float) + (s0 < nq[k] ? s0 * (int)sizeof(float) : kPastLattice), e);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the rows have landed ...
+        if (lane == 0) {                                     // ... before they are counted
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (tq[k] >= 0)
+                    __hip_atomic_fetch_add(p.chunk + bq[k] * p.nchunk + cq[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// the scout of a direction: polls the sample's chunk counters in order, publishes "chunks complete" in LDS
+__device__ __forceinline__ void blank_pool_scout(const BlankParams &p, int b, int Tb, int *verified)
+{
+    const int H = (Tb + 1) >> 1, nch = (H + kPoolChunk - 1) / kPoolChunk;
+    const int *cnt = p.chunk + b * p.nchunk;
+    for (int c = 0; c < nch; ++c) {
+        const int want = blank_chunk_rows(Tb, c);
+        bool ok = false;
+        for (int it = 0; it < kSpinLimit; ++it) {
+            if (agent_load(cnt + c) >= want) { ok = true; break; }
+            if ((it & 255) == 255 && agent_load(p.sync) != 0) break;   // somebody already gave up
+            __builtin_amdgcn_s_sleep(20);
+        }
+        if (!ok) { agent_store(p.sync, 1); raise_status(p.counter, kStatusBlankStarved); return; }   // (the loaders' waits run out)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane_id() == 0) wg_store(verified, c + 1);
+    }
+}
+
+// data loader j (of kPoolLoaders) of direction dir: rows j, j + kPoolLoaders, ... of the chain's step order, K floats per
+// lane from the workspace where the pool left them, kLoadAhead rows in flight, into the ring as soon as the chain has left
+// the slot.  A row's load is ISSUED only once its chunk is known complete.
+template <int K>
+__device__ __forceinline__ void blank_pool_loader(const BlankParams &p, int b, int Tb, int L, int dir, int j, const FusedLds &f)
+{
+    constexpr int R = kRingRows / K, P = kLoadAhead, NL = kPoolLoaders;
+    const int lane = lane_id(), s0 = lane * K, n = 2 * L + 1;
+    float *ring = f.ring(dir) + s0;
+    int *done_flag = f.flags + 4 * dir + j;
+    const int *consumed = f.flags + 4 * dir + 3;
+    const int *verified = f.flags + 12 + dir;
+    const __amdgpu_buffer_rsrc_t ersrc = lattice_rsrc(p.em + (int64_t)b * p.T * p.NSP, p.T, p.NSP);
+    const int lane_off = s0 < n ? s0 * (int)sizeof(float) : kPastLattice;
+    int seen = 0, chunks = 0, done = 0;
+    bool dead = false;                                       // a bounded wait ran out (never observed): stop, say so
+    auto fetch = [&](float (&y)[K], int r) {                 // row r of the step order (past the end: the last row again)
+        const int rr = r < Tb ? r : Tb - 1;
+        const int c = min(rr, Tb - 1 - rr) / kPoolChunk;     // the chunk the pool counts this row in
+        if (c >= chunks && !dead && !lds_wait_ge_quiet(verified, c + 1, chunks)) dead = true;
+        agent_load_row<K>(ersrc, (dir == 0 ? rr : Tb - 1 - rr) * p.NSP * (int)sizeof(float) + lane_off, y);
+    };
+    float y[P][K];
+#pragma unroll
+    for (int q = 0; q < P; ++q) fetch(y[q], j + NL * q);
+    for (int r = j; r < Tb && !dead; r += NL * P) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int rr = r + NL * q;
+            if (rr < Tb && !dead) {                          // wave-uniform
+                float e[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) e[k] = s0 + k < n ? y[q][k] : kNegB;   // (lanes past the states read 0)
+                if (rr - R + 1 > seen && !lds_wait_ge_quiet(consumed, rr - R + 1, seen)) dead = true;   // slot still being read
+                lds_put<K>(ring + (rr & (R - 1)) * p.NSP, e);
+                ++done;                                      // (LDS keeps a wave's program order: row, then count)
+                if (lane == 0 && !dead) wg_store(done_flag, done);
+            }
+            fetch(y[q], rr + NL * P);
+        }
+    }
+    if (dead) { agent_store(p.sync, 1); raise_status(p.counter, kStatusBlankStarved); }
+}
+
+template <int K, bool FWD, int NL>
 __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, int Tb, int L, float (&a)[K], const FusedLds &f, bool once)
 {
+    constexpr int kLoaders = NL;                             // data loader waves of this direction (shadows the global)
     constexpr int R = kRingRows / K, G = kGroup < R / 2 ? kGroup : R / 2;
     static_assert(G <= R / 2, "a group must fit in the ring twice");
     const int lane = lane_id(), s0 = lane * K, n = 2 * L + 1, dir = FWD ? 0 : 1;
@@ -618,6 +793,12 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
     // rows <= last of the step order are in the ring: loader j has then finished (last - j)/kLoaders + 1 rows
     int have[kLoaders] = {};
     unsigned long long waited = 0, polls = 0;                // (diagnostics)
+#ifdef CTC_AMD_DIAGNOSTICS
+    const bool probe = FWD && b == 0 && (p.debug & 256);     // (diagnostics build: per-group cycle breakdown, see the main loop)
+#else
+    constexpr bool probe = false;
+#endif
+    unsigned long long pr[2][6] = {};
     auto need_rows = [&](int last) {
         int need[kLoaders];
         bool all = true;
@@ -678,15 +859,21 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
         const int hi = (seg == 0 && H > 0) ? (H < Tb ? H : Tb) : Tb;
         for (; i + G <= hi; i += G) {
             if (FWD && b == 0 && (i - 1) % 256 < G) bstamp(p, 1 + (i - 1) / 256);
+            // (diagnostics, CTC_AMD_BLANK_DEBUG & 256: where a group of G steps of sample 0's alpha chain spends its cycles)
+            const unsigned long long q0 = probe ? __builtin_amdgcn_s_memtime() : 0;
             need_rows(i + G - 1);
+            const unsigned long long q1 = probe ? __builtin_amdgcn_s_memtime() : 0;
             float e[G][K];
 #pragma unroll
             for (int j = 0; j < G; ++j) em_row(e[j], i + j);
+            if (probe) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long q2 = probe ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
             for (int j = 0; j < G; ++j) {
                 blank_step<K, FWD>(a, e[j], skip);
                 store(i + j, e[j]);
             }
+            const unsigned long long q3 = probe ? __builtin_amdgcn_s_memtime() : 0;
             if (lane == 0) wg_store(consumed, i + G);        // the loaders may refill these slots
             // Only stores go through this wave's vector-memory counter, it retires in order, and a step
             // issues at least one: at most kLandLag outstanding => the rows of the steps before
@@ -695,9 +882,16 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
             // also store their emission rows have kLandLag more in the last kLandLag steps)
             if (i + G <= H) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kHalfLattice ? kLandLag / 2 : kLandLag) + kLandLag) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kHalfLattice ? kLandLag / 2 : kLandLag) : "memory");
+            const unsigned long long q4 = probe ? __builtin_amdgcn_s_memtime() : 0;
             if (lane == 0 && i + G > kLandLag) {
                 agent_store(prog, i + G - kLandLag);
                 if (once) wg_store(landed, i + G - kLandLag);
+            }
+            if (probe) {
+                const unsigned long long q5 = __builtin_amdgcn_s_memtime();
+                const int half = 2 * i >= Tb ? 1 : 0;         // first half: worker pool idle; second: beside the streaming workers
+                pr[half][0] += q1 - q0; pr[half][1] += q2 - q1; pr[half][2] += q3 - q2; pr[half][3] += q4 - q3; pr[half][4] += q5 - q4;
+                pr[half][5] += 1;
             }
         }
         if (i < hi) {
@@ -724,6 +918,10 @@ __device__ __forceinline__ void blank_chain_fused(const BlankParams &p, int b, i
     if (FWD && b == 0 && (p.debug & 128) && lane == 0) {
         reinterpret_cast<unsigned long long *>(p.counter)[8 + 16] = waited;
         reinterpret_cast<unsigned long long *>(p.counter)[8 + 17] = polls;
+    }
+    if (probe && lane == 0) {                                // (the probe reuses the timeline's slots 0..11: run them apart)
+        for (int h = 0; h < 2; ++h)
+            for (int k = 0; k < 6; ++k) reinterpret_cast<unsigned long long *>(p.counter)[8 + 6 * h + k] = pr[h][k];
     }
     if (lane == 0) agent_store(prog, starved ? -1 : Tb);     // (a starved chain never releases its rows)
     if (lane == 0 && once && !starved) wg_store(landed, Tb);
@@ -1282,17 +1480,22 @@ __global__ __launch_bounds__(kFusedThreads) void blank_fused_kernel(BlankParams 
         static_assert(kFusedWaves == 2 + 2 * kLoaders, "two chains and their loaders");
         // waves 0 / 1: the chains; waves 2, 4, 6 / 3, 5, 7: the loaders of the alpha / beta direction
         const int dir = w & 1, role = w >> 1;                // role 0: chain, 1..kLoaders: loader role-1
+        constexpr bool kPool = VEC4 && kPoolGather;          // the worker pool gathers the emission rows (see kPoolGather)
+        constexpr int NL = kPool ? kPoolLoaders : kLoaders;  // data loader waves per direction
         if (role == 0) {
             __builtin_amdgcn_s_setprio(3);
             if (dir == 0) {
-                if (run) blank_chain_fused<K, true>(p, b, Tb, L, a, f, VEC4 && kGatherOnce);
+                if (run) blank_chain_fused<K, true, NL>(p, b, Tb, L, a, f, VEC4 && kGatherOnce && !kPool);
                 blank_publish<K>(p, b, ok, Tb, L, a);
             } else if (run) {
-                blank_chain_fused<K, false>(p, b, Tb, L, a, f, VEC4 && kGatherOnce);
+                blank_chain_fused<K, false, NL>(p, b, Tb, L, a, f, VEC4 && kGatherOnce && !kPool);
             }
         } else if (run) {
             const int j = role - 1;
-            if (VEC4) {
+            if (kPool) {
+                if (j < kPoolLoaders) blank_pool_loader<K>(p, b, Tb, L, dir, j, f);
+                else blank_pool_scout(p, b, Tb, f.flags + 12 + dir);
+            } else if (VEC4) {
                 float *stage = f.ring(2) + (kLoaders * dir + j) * 4 * kWave * kMaxV4;
                 blank_loader_rows<K>(p, b, Tb, L, dir, j, f, stage);
             } else {
@@ -1320,6 +1523,12 @@ __global__ __launch_bounds__(kFusedThreads) void blank_fused_kernel(BlankParams 
 #pragma unroll
     for (int sh = 1; sh < kWave; sh <<= 1) m0 = min(m0, __shfl_xor(m0, sh));
     m0 = __builtin_amdgcn_readfirstlane(m0);
+    if (VEC4 && kPoolGather) {                               // the pool's first job: the emission rows, in the chains' order
+        blank_pool_gather<K>(p, wid, nw, kHalfLattice ? gam + 2 * p.NSP : occ);
+        if (!kHalfLattice)
+            for (int c = lane; c < C4; c += kWave) occ[c] = 0.f;
+        if (wid == 0) bstamp(p, 11);
+    }
     if (kHalfLattice) blank_grad_pairs<K, VEC4>(p, m0 * 2 * p.B + wid, nw, 2 * ((p.T + 1) >> 1) * p.B, occ, gam, gam + 2 * p.NSP);
     else blank_grad_rows<K, VEC4, true>(p, m0 * 2 * p.B + wid, nw, 2 * p.T * p.B, occ, gam);
     if (wid == 0) bstamp(p, 12);
@@ -1380,6 +1589,8 @@ static int run_blank(BlankParams &p, hipStream_t s)
     p.Bp = (p.B + 63) & ~63;
     p.sync = reinterpret_cast<int *>(p.meta + p.Bp);
     p.nsync = blank_sync_ints(p.T, p.B);
+    p.nchunk = blank_pool_chunks(p.T);
+    p.chunk = p.sync + kSyncHead + 2 * p.Bp * kProgPitch;
     static const int debug = diag_env("CTC_AMD_BLANK_DEBUG");
     p.debug = debug;
     const size_t row_lds = (((p.C + 3) & ~3) + 2 * p.NSP) * sizeof(float);   // a grad wave's occ[] + gam[] + nxt[]

@@ -33,6 +33,16 @@ ws[64:256].zero_()
 wl.fused(loss.data_ptr(), ws, s)
 torch.cuda.synchronize()
 st = ws[:256].cpu().numpy()[64:256].view(np.uint64).astype(np.int64)
+if int(os.environ.get("CTC_AMD_BLANK_DEBUG", "0")) & 256:     # the chain probe: cycles per group of 16 steps, by what they went to
+    names = ["emission rows there? (flag polls, waits for loaders)", "ring reads (16 x ds_read_b128, waited for)",
+             "16 steps: arithmetic + store issue", "consumed flag + store-landing wait (s_waitcnt vmcnt)", "progress publication"]
+    for h, what in enumerate(("first half (worker pool idle)", "second half (beside the streaming workers)")):
+        n = max(int(st[6 * h + 5]), 1)
+        tot = sum(int(st[6 * h + k]) for k in range(5))
+        print("  alpha chain of sample 0, %s: %d groups of 16 steps, %.0f cycles per group = %.1f per step" % (what, n, tot / n, tot / n / 16))
+        for k in range(5):
+            print("      %-58s %7.0f cycles per group (%4.1f %%)" % (names[k], st[6 * h + k] / n, 100.0 * st[6 * h + k] / max(tot, 1)))
+    sys.exit(0)
 t0 = min(v for v in st[:16] if v > 0)
 print("  alpha chain of sample 0: %d waits for emission rows, %d shader clocks in them" % (st[17], st[16]))
 for i, v in enumerate(st[:16]):
