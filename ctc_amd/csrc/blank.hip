@@ -361,6 +361,29 @@ __device__ __forceinline__ void blank_state_flags(const BlankParams &p, int b, i
 // instead of 12 (they are half of the step's issue time).  Where the s-2 edge does not exist (repeated label) the
 // second term is the neighbour itself.  Costs one more fp32 rounding on that path (the blank's value is rounded before
 // it is reused); the workers' recomputed rows go through this same function, so they still match the chains' bit for bit.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+#ifdef CTC_X_SCALAR_STEP
+constexpr bool kPackedStep = false;
+#else
+constexpr bool kPackedStep = true;
+#endif
+// two two-term log-sum-exps at once: the subtractions and additions go through the packed fp32 pipe (v_pk_add_f32: two
+// lanes' worth per instruction), the maxima and the transcendentals stay single -- 9 instead of 12 VALU operations
+__device__ __forceinline__ v2f_t lse2_2x2(v2f_t a, v2f_t b)
+{
+    const v2f_t d = a - b;
+    v2f_t t;
+    t.x = __builtin_amdgcn_exp2f(-fabsf(d.x));
+    t.y = __builtin_amdgcn_exp2f(-fabsf(d.y));
+    t += 1.0f;
+    v2f_t l, m;
+    l.x = __builtin_amdgcn_logf(t.x);
+    l.y = __builtin_amdgcn_logf(t.y);
+    m.x = fmaxf(a.x, b.x);
+    m.y = fmaxf(a.y, b.y);
+    return m + l;
+}
+
 template <int K, bool FWD>
 __device__ __forceinline__ void blank_step(float (&a)[K], const float (&e)[K], const bool (&skip)[K])
 {
@@ -368,22 +391,44 @@ __device__ __forceinline__ void blank_step(float (&a)[K], const float (&e)[K], c
     float pre[K];
     // blank states first (k even): two predecessors, no skip.  States beyond n carry the sentinel emission and just
     // sink (stay finite: they lose 1e30 per step, fp32 holds that for any T); no per-state masking or clamping.
+    // (the states are taken in pairs (k, k + 2) through lse2_2x2; the same arithmetic, operation by operation, as
+    // lse2_2 -- the workers' recomputed rows go through this same function)
     if (FWD) {
         const float n1 = wave_shr1(a[K - 1], kNegB);          // previous lane's last (label) state
+        if constexpr (K == 4 && kPackedStep) {
+            const v2f_t pb = lse2_2x2(v2f_t{a[0], a[2]}, v2f_t{n1, a[1]});
+            pre[0] = pb.x; pre[2] = pb.y;
+            const v2f_t pl = lse2_2x2(v2f_t{a[1], a[3]}, v2f_t{skip[1] ? pre[0] : a[0], skip[3] ? pre[2] : a[2]});
+            pre[1] = pl.x; pre[3] = pl.y;
+        } else {
 #pragma unroll
-        for (int k = 0; k < K; k += 2) pre[k] = lse2_2(a[k], k >= 1 ? a[k - 1] : n1);
+            for (int k = 0; k < K; k += 2) pre[k] = lse2_2(a[k], k >= 1 ? a[k - 1] : n1);
 #pragma unroll
-        for (int k = 1; k < K; k += 2) pre[k] = lse2_2(a[k], skip[k] ? pre[k - 1] : a[k - 1]);
+            for (int k = 1; k < K; k += 2) pre[k] = lse2_2(a[k], skip[k] ? pre[k - 1] : a[k - 1]);
+        }
     } else {
         const float n1 = wave_shl1(a[0], kNegB);              // next lane's first (blank) state
+        if constexpr (K == 4 && kPackedStep) {
+            const v2f_t pb = lse2_2x2(v2f_t{a[0], a[2]}, v2f_t{a[1], a[3]});
+            pre[0] = pb.x; pre[2] = pb.y;
+            const float nb = wave_shl1(pre[0], kNegB);        // ... and what that blank comes from
+            const v2f_t pl = lse2_2x2(v2f_t{a[1], a[3]}, v2f_t{skip[1] ? pre[2] : a[2], skip[3] ? nb : n1});
+            pre[1] = pl.x; pre[3] = pl.y;
+        } else {
 #pragma unroll
-        for (int k = 0; k < K; k += 2) pre[k] = lse2_2(a[k], a[k + 1]);
-        const float nb = wave_shl1(pre[0], kNegB);            // ... and what that blank comes from
+            for (int k = 0; k < K; k += 2) pre[k] = lse2_2(a[k], a[k + 1]);
+            const float nb = wave_shl1(pre[0], kNegB);        // ... and what that blank comes from
 #pragma unroll
-        for (int k = 1; k < K; k += 2) pre[k] = lse2_2(a[k], skip[k] ? (k + 1 < K ? pre[k + 1] : nb) : (k + 1 < K ? a[k + 1] : n1));
+            for (int k = 1; k < K; k += 2) pre[k] = lse2_2(a[k], skip[k] ? (k + 1 < K ? pre[k + 1] : nb) : (k + 1 < K ? a[k + 1] : n1));
+        }
     }
+    if constexpr (K == 4 && kPackedStep) {
+        const v2f_t s0 = v2f_t{pre[0], pre[1]} + v2f_t{e[0], e[1]}, s1 = v2f_t{pre[2], pre[3]} + v2f_t{e[2], e[3]};
+        a[0] = s0.x; a[1] = s0.y; a[2] = s1.x; a[3] = s1.y;
+    } else {
 #pragma unroll
-    for (int k = 0; k < K; ++k) a[k] = pre[k] + e[k];
+        for (int k = 0; k < K; ++k) a[k] = pre[k] + e[k];
+    }
 }
 
 // the first row: the two entry states only
