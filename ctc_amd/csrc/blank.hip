@@ -1508,7 +1508,7 @@ __global__ __launch_bounds__(kGradWaves * kWave) void blank_grad_kernel(BlankPar
 }
 
 // ---- fused schedule: the launch -----------------------------------------------------------------
-template <int K, bool VEC4>
+template <int K, bool VEC4, bool POOL = false>
 __global__ __launch_bounds__(kFusedThreads) void blank_fused_kernel(BlankParams p)
 {
     extern __shared__ float4 s_buf4[];
@@ -1525,7 +1525,7 @@ __global__ __launch_bounds__(kFusedThreads) void blank_fused_kernel(BlankParams 
         static_assert(kFusedWaves == 2 + 2 * kLoaders, "two chains and their loaders");
         // waves 0 / 1: the chains; waves 2, 4, 6 / 3, 5, 7: the loaders of the alpha / beta direction
         const int dir = w & 1, role = w >> 1;                // role 0: chain, 1..kLoaders: loader role-1
-        constexpr bool kPool = VEC4 && kPoolGather;          // the worker pool gathers the emission rows (see kPoolGather)
+        constexpr bool kPool = VEC4 && POOL && kPoolGather;  // the worker pool gathers the emission rows (see kPoolGather)
         constexpr int NL = kPool ? kPoolLoaders : kLoaders;  // data loader waves per direction
         if (role == 0) {
             __builtin_amdgcn_s_setprio(3);
@@ -1568,7 +1568,7 @@ __global__ __launch_bounds__(kFusedThreads) void blank_fused_kernel(BlankParams 
 #pragma unroll
     for (int sh = 1; sh < kWave; sh <<= 1) m0 = min(m0, __shfl_xor(m0, sh));
     m0 = __builtin_amdgcn_readfirstlane(m0);
-    if (VEC4 && kPoolGather) {                               // the pool's first job: the emission rows, in the chains' order
+    if (VEC4 && POOL && kPoolGather) {                       // the pool's first job: the emission rows, in the chains' order
         blank_pool_gather<K>(p, wid, nw, kHalfLattice ? gam + 2 * p.NSP : occ);
         if (!kHalfLattice)
             for (int c = lane; c < C4; c += kWave) occ[c] = 0.f;
@@ -1604,7 +1604,8 @@ static int fused_capacity(size_t lds)
     return cap;
 }
 
-// schedule of the long-sequence path: -1 the library's own choice, 1 / 0 force / forbid the persistent launch
+// schedule of the long-sequence path: -1 the library's own choice, 1 / 0 force / forbid the persistent launch, 2 force
+// it with the worker pool gathering the emission rows
 // (ctc_amd_blank_set_schedule; the initial value comes from CTC_AMD_BLANK_FUSED, read once)
 static std::atomic<int> g_blank_schedule{-2};
 static int blank_schedule()
@@ -1651,7 +1652,7 @@ static int run_blank(BlankParams &p, hipStream_t s)
     // 132/111, 32x2000x50 352/285 (rows too wide for the float4 loaders); over T at 64x1000x100: 51.5/51.8 at 128,
     // 74/82 at 256, 119/146 at 512.  ctc_amd_blank_set_schedule(1 / 0) forces / forbids it (tests, measurements).
     const int schedule = blank_schedule();
-    const bool forced = schedule == 1, forbidden = schedule == 0;
+    const bool forced = schedule >= 1, forbidden = schedule == 0, forced_pool = schedule == 2;
     if (p.grad && !forbidden && p.T >= kFusedMinT && (int64_t)p.T * p.NSP * 4 < kPastLattice &&
         (int64_t)2 * p.T * p.B + 4096 < ((int64_t)1 << 31)) {
         // more than half of a CU's LDS per workgroup: one workgroup per CU, the chains share their SIMDs with nobody
@@ -1667,6 +1668,15 @@ static int run_blank(BlankParams &p, hipStream_t s)
             int rc = launch<blank_tables_kernel>(dim3(p.B), dim3(256), p.NSP * sizeof(int), s, p);
             if (rc) return rc;
             const dim3 grid(cap), block(kFusedThreads);
+            // The worker pool gathers the emission rows (kPoolGather) where the pool is large against the samples and the
+            // sequences long: tools/blank_sweep.py, T = 1000, us per call pool / loaders -- B=64 C=1000 S=100 209 / 220
+            // (T=2000: 384 / 432), but 32x1000x100 175 / 170, 48x640x100 186 / 184 (ties), 96x1000x100 410 / 378,
+            // 128x1000x100 489 / 436 (too few workers per sample), 64x800x200 362 / 289 (eight states per lane), and
+            // T=512 123 / 119, T=256 89 / 74 (the chains' first steps wait for the pool's first rows).
+            // (ctc_amd_blank_set_schedule(2) forces the pool gather on every float4 shape: tests)
+            const bool pool = kPoolGather && vec4 &&
+                              (forced_pool || (K == 4 && p.T >= 800 && 4 * p.B >= cap && 5 * p.B <= 2 * (cap - p.B)));
+            if (pool) return launch<blank_fused_kernel<K, true, true>>(grid, block, lds, s, p);
             if (vec4) return launch<blank_fused_kernel<K, true>>(grid, block, lds, s, p);
             return launch<blank_fused_kernel<K, false>>(grid, block, lds, s, p);
         }
@@ -1719,7 +1729,7 @@ extern "C" int ctc_amd_blank_loss_grad(const float *log_probs, int64_t stride_t,
 
 extern "C" int ctc_amd_blank_set_schedule(int mode)
 {
-    if (mode < -1 || mode > 1) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (mode < -1 || mode > 2) return CTC_AMD_ERR_BAD_ARGUMENT;
     g_blank_schedule.store(mode, std::memory_order_relaxed);
     return 0;
 }

@@ -112,7 +112,8 @@ def collective_gate(variant, batch, device=None, launch_stream=None, timeout_us=
 
 
 def set_blank_schedule(mode):
-    """-1: the library chooses (default); 1 / 0: force / forbid the persistent blank-CTC launch."""
+    """-1: the library chooses (default); 1 / 0: force / forbid the persistent blank-CTC launch; 2: force it with the
+    worker pool gathering the emission rows."""
     _lib.check(_lib.load().ctc_amd_blank_set_schedule(int(mode)), "ctc_amd_blank_set_schedule")
 
 

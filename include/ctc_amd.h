@@ -128,7 +128,8 @@ int ctc_amd_blank_loss_grad(const float *log_probs, int64_t stride_t, int64_t st
                             void *workspace, void *stream);
 
 /* Schedule of the long-sequence blank-CTC path: -1 = the library's own choice (default), 1 / 0 = force /
- * forbid the single persistent launch (tests and measurements; process-wide, thread-safe).  The
+ * forbid the single persistent launch, 2 = force it with the worker pool gathering the emission rows (the
+ * library's own choice around BASELINE config 5) (tests and measurements; process-wide, thread-safe).  The
  * environment variable CTC_AMD_BLANK_FUSED=1 / 0, read ONCE at first use, sets the initial value. */
 int ctc_amd_blank_set_schedule(int mode);
 

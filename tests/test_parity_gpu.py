@@ -247,16 +247,17 @@ def test_blank_golden(golden, dev, name):
                                    (600, 3, 24, 30),      # long sequences; 2 states per lane (4 and 8 are the
                                    (1100, 3, 16, 40)])    # two shapes before)
 @pytest.mark.parametrize("var_T", [False, True])
-@pytest.mark.parametrize("schedule", ["auto", "persistent"])
+@pytest.mark.parametrize("schedule", ["auto", "persistent", "pool"])
 def test_blank_vs_torch_cpu(dev, shape, var_T, schedule, monkeypatch):
     """the third-party arithmetic itself (torch CPU F.ctc_loss) is the comparator here.  `persistent` forces
-    the single persistent launch of blank.hip (the library picks it by itself only for config-5-like batches)"""
+    the single persistent launch of blank.hip (the library picks it by itself only for config-5-like batches),
+    `pool` forces it with the worker pool gathering the emission rows (float4-able rows: C % 4 == 0)"""
     import ctc_amd
     T, B, C, S = shape
-    if schedule == "persistent":
-        if T < 128:
-            pytest.skip("the persistent launch needs T >= 128")
-        _schedule(monkeypatch, 1)
+    if schedule in ("persistent", "pool"):
+        if T < 128 or (schedule == "pool" and C % 4):
+            pytest.skip("the persistent launch needs T >= 128 (the pool gather: float4 rows)")
+        _schedule(monkeypatch, 1 if schedule == "persistent" else 2)
     else:
         _schedule(monkeypatch, -1)
     lp, tgt, Tb, L = synth_blank(sum(shape), T, B, C, S, var_T=var_T)
@@ -280,7 +281,7 @@ def test_blank_vs_torch_cpu(dev, shape, var_T, schedule, monkeypatch):
             assert np.abs(r["grad"][:, b]).max() == 0.0     # documented: zero, where torch gives NaN
 
 
-@pytest.mark.parametrize("schedule", ["1", "0"])
+@pytest.mark.parametrize("schedule", ["1", "0", "2"])
 def test_blank_fused_schedule_edge_cases(dev, schedule, monkeypatch):
     """the single persistent launch (and the three launches): ragged lengths, a one-frame sample, an empty
     target, a sample without any alignment and an empty input in one batch, against the float64 oracle"""
@@ -328,7 +329,7 @@ def test_blank_persistent_launch_row_pairs(dev, T, monkeypatch):
         fin = np.isfinite(ref["nll"])
         assert fin[:8].all()
         got = {}
-        for schedule in (1, 0):
+        for schedule in (1, 0, 2):                            # (2: the worker pool gathers the emission rows)
             _schedule(monkeypatch, schedule)
             r = run_hip(ctc_amd.blank_ctc_loss, lp, tgt, Tb, L, dev)
             assert (np.isinf(r["nll"]) == ~fin).all()
@@ -338,6 +339,7 @@ def test_blank_persistent_launch_row_pairs(dev, T, monkeypatch):
                 assert np.abs(r["grad"][int(Tb[b]):, b]).max(initial=0.0) == 0.0
             got[schedule] = r
         assert np.abs(got[1]["grad"] - got[0]["grad"]).max() < 2e-6 * 64.0 / B
+        assert np.abs(got[2]["grad"] - got[1]["grad"]).max() == 0.0    # same chains, same rows: bit for bit
 
 
 @pytest.mark.parametrize("shape", [(40, 3, 12, 6), (150, 3, 1300, 12)])   # three launches; persistent launch with rows
