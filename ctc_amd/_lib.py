@@ -29,6 +29,8 @@ PROTOTYPES = {
                                        _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctc_amd_scale_grad": (_int, [_vp, _vp, _sz, _vp]),
     "ctc_amd_collective_gate": (_int, [_vp, _int, _int, _vp]),
+    "ctc_amd_lstm_cell_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp,
+                                      _vp, _i64, _int, _f32, _vp]),
     "ctc_amd_dedup_multihot_targets": (_int, [_vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ctc_amd_blank_set_schedule": (_int, [_int]),
     "ctc_amd_workspace_status": (_int, [_vp, _int, _vp, ctypes.POINTER(ctypes.c_uint)]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libctc_amd.so")
-SOURCES = ["api.hip", "noblank.hip", "binary.hip", "blank.hip", "decode.hip", "targets.hip"]
+SOURCES = ["api.hip", "noblank.hip", "binary.hip", "blank.hip", "decode.hip", "targets.hip", "producer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

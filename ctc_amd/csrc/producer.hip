@@ -1,0 +1,121 @@
+// The step immediately upstream of the loss: the reference's LSTM_cell.forward (LSTM.py:39-51) runs
+//     for time in range(temporal):  v = self.v(feat[time]);  v_hsn, v_csn = self.v_cell(v, (v_hsn, v_csn));
+//                                   v_series[time] = v_hsn
+// i.e. one torch.nn.LSTMCell step per frame whose hidden state IS the logits row the CTC losses read.  This file
+// is that step as ONE launch: both gate products, the cell update, and the hidden state written straight into
+// v_series[time] -- in the row layout the loss kernels want (unit stride over classes, any row pitch; pad columns
+// behind the last class filled with a value of the caller's choice: a pitch of C + 1 with -1e30 there turns an
+// odd class count (the reference's 33) into the even, 8-byte aligned rows of the four-rows-per-wave loss kernel
+// without changing a single loss or gradient value -- softmax gives that column exactly 0).
+//
+// torch.nn.LSTMCell semantics:  gates = x W_ih^T + b_ih + h W_hh^T + b_hh, chunks (i, f, g, o) of H rows each;
+//     i, f, o = sigmoid, g = tanh;   c' = f c + i g;   h' = o tanh(c').
+//
+// Small and latency-bound at the reference's sizes (B = 10, H = 33: 17 kFLOP per step) and still small at the
+// benchmark's (B = 256, H = 158: 0.1 GFLOP): one workgroup per kLstmSamples samples stages [x | h] in LDS, every
+// thread owns gate rows r = tid, tid + 256, ... of [W_ih | W_hh] and walks them once for all staged samples (the
+// weights, <= 0.8 MB, stay in L2; the staged inputs are LDS broadcasts), the pre-activations meet in LDS and one
+// thread per hidden unit finishes the cell.  fp32 fma chains in k order (W_ih part, then W_hh part, then the biases).
+#include "common.hpp"
+#include "launch.hpp"
+
+namespace ctc {
+
+constexpr int kLstmSamples = 8, kLstmThreads = 256;
+
+struct LstmParams {
+    const float *x, *h, *c, *w_ih, *w_hh, *b_ih, *b_hh;
+    int B, I, H;
+    float *h_out, *c_out, *gates;                            // gates: optional [B][4H] activations (i, f, g, o)
+    float *series;                                           // optional: row b at series + b * series_stride_b
+    int64_t series_stride_b;
+    int series_cols;                                         // columns [H, series_cols) of a row get pad_value
+    float pad_value;
+};
+
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+__global__ __launch_bounds__(kLstmThreads) void lstm_cell_step_kernel(LstmParams p)
+{
+    extern __shared__ float lstm_smem[];
+    const int K = p.I + p.H, G = 4 * p.H;
+    float *xh = lstm_smem;                                   // [kLstmSamples][K]
+    float *pre = xh + kLstmSamples * K;                      // [kLstmSamples][G]
+    const int tid = threadIdx.x, b0 = blockIdx.x * kLstmSamples;
+    const int ns = min(kLstmSamples, p.B - b0);
+    for (int i = tid; i < kLstmSamples * K; i += kLstmThreads) {
+        const int s = i / K, k = i - s * K;
+        float v = 0.f;
+        if (s < ns) v = k < p.I ? p.x[(size_t)(b0 + s) * p.I + k] : p.h[(size_t)(b0 + s) * p.H + (k - p.I)];
+        xh[i] = v;
+    }
+    __syncthreads();
+    for (int r = tid; r < G; r += kLstmThreads) {
+        float acc[kLstmSamples];
+#pragma unroll
+        for (int s = 0; s < kLstmSamples; ++s) acc[s] = 0.f;
+        const float *wi = p.w_ih + (size_t)r * p.I, *wh = p.w_hh + (size_t)r * p.H;
+#pragma unroll 4
+        for (int k = 0; k < p.I; ++k) {
+            const float w = wi[k];
+#pragma unroll
+            for (int s = 0; s < kLstmSamples; ++s) acc[s] = __builtin_fmaf(w, xh[s * K + k], acc[s]);
+        }
+#pragma unroll 4
+        for (int k = 0; k < p.H; ++k) {
+            const float w = wh[k];
+#pragma unroll
+            for (int s = 0; s < kLstmSamples; ++s) acc[s] = __builtin_fmaf(w, xh[s * K + p.I + k], acc[s]);
+        }
+        const float bias = p.b_ih[r] + p.b_hh[r];
+#pragma unroll
+        for (int s = 0; s < kLstmSamples; ++s) pre[s * G + r] = acc[s] + bias;
+    }
+    __syncthreads();
+    for (int i = tid; i < ns * p.H; i += kLstmThreads) {
+        const int s = i / p.H, j = i - s * p.H, b = b0 + s;
+        const float *g4 = pre + s * G;
+        const float gi = sigmoid_f(g4[j]), gf = sigmoid_f(g4[p.H + j]), gg = tanhf(g4[2 * p.H + j]), go = sigmoid_f(g4[3 * p.H + j]);
+        const float cn = __builtin_fmaf(gf, p.c[(size_t)b * p.H + j], gi * gg);
+        const float hn = go * tanhf(cn);
+        p.c_out[(size_t)b * p.H + j] = cn;
+        p.h_out[(size_t)b * p.H + j] = hn;
+        if (p.series) p.series[b * p.series_stride_b + j] = hn;
+        if (p.gates) {
+            float *q = p.gates + (size_t)b * G;
+            q[j] = gi; q[p.H + j] = gf; q[2 * p.H + j] = gg; q[3 * p.H + j] = go;
+        }
+    }
+    if (p.series && p.series_cols > p.H) {
+        const int np = p.series_cols - p.H;
+        for (int i = tid; i < ns * np; i += kLstmThreads) {
+            const int s = i / np, j = p.H + (i - s * np);
+            p.series[(b0 + s) * p.series_stride_b + j] = p.pad_value;
+        }
+    }
+}
+
+}  // namespace ctc
+
+using namespace ctc;
+
+extern "C" int ctc_amd_lstm_cell_step(const float *x, const float *h, const float *c,
+                                      const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                                      int B, int I, int H,
+                                      float *h_out, float *c_out, float *gates_out,
+                                      float *series_row, int64_t series_stride_b, int series_cols, float pad_value,
+                                      void *stream)
+{
+    if (!x || !h || !c || !w_ih || !w_hh || !b_ih || !b_hh || !h_out || !c_out) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (B < 1 || I < 1 || H < 1) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (series_row && (series_cols < H || series_stride_b < series_cols)) return CTC_AMD_ERR_BAD_ARGUMENT;
+    const size_t smem = (size_t)kLstmSamples * ((size_t)I + H + 4 * (size_t)H) * sizeof(float);
+    if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    LstmParams p;
+    p.x = x; p.h = h; p.c = c; p.w_ih = w_ih; p.w_hh = w_hh; p.b_ih = b_ih; p.b_hh = b_hh;
+    p.B = B; p.I = I; p.H = H;
+    p.h_out = h_out; p.c_out = c_out; p.gates = gates_out;
+    p.series = series_row; p.series_stride_b = series_stride_b; p.series_cols = series_cols; p.pad_value = pad_value;
+    return launch<lstm_cell_step_kernel>(dim3((B + kLstmSamples - 1) / kLstmSamples), dim3(kLstmThreads), smem,
+                                         static_cast<hipStream_t>(stream), p);
+}

@@ -199,6 +199,23 @@ int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int64_t stride_
                                float *nll, float *gamma,
                                void *workspace, void *stream);
 
+/* The producer step of the logits: one torch.nn.LSTMCell step of the reference's LSTM_cell.forward
+ * (LSTM.py:39-51: `v_hsn, v_csn = self.v_cell(v, (v_hsn, v_csn)); v_series[time] = v_hsn`), fused with the write of
+ * the hidden state into the logits tensor the losses read.
+ *   x [B,I], h [B,H], c [B,H]: the cell's input and state (contiguous fp32);  w_ih [4H,I], w_hh [4H,H], b_ih, b_hh [4H]:
+ *   nn.LSTMCell's parameters (gate order i, f, g, o);  h_out, c_out [B,H]: the new state (may alias h / c);
+ *   gates_out [B,4H] or NULL: the gate activations (what a backward pass needs);
+ *   series_row or NULL: row b of v_series[time] starts at series_row + b * series_stride_b; columns [0,H) get the new
+ *   hidden state, columns [H, series_cols) get pad_value (a pitch of H + 1 with pad_value = -1e30 gives an odd class
+ *   count the even, 8-byte aligned rows of the fastest loss kernel; the padded class has softmax 0: no loss or gradient
+ *   value changes).  gates = x W_ih^T + b_ih + h W_hh^T + b_hh; c' = sigma(f) c + sigma(i) tanh(g); h' = sigma(o) tanh(c'). */
+int ctc_amd_lstm_cell_step(const float *x, const float *h, const float *c,
+                           const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                           int B, int I, int H,
+                           float *h_out, float *c_out, float *gates_out,
+                           float *series_row, int64_t series_stride_b, int series_cols, float pad_value,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

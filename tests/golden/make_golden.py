@@ -275,13 +275,41 @@ def F6(NB, NBB):
     save("dedup_targets", **arrs)
 
 
+def F7(NB, NBB):
+    """the producer of the logits: the reference's OWN LSTM_cell (LSTM.py, imported unmodified, `.cuda()`
+    an identity) in eval mode (BatchNorm on its running statistics, Dropout off: deterministic) at its production
+    sizes -- extract_feat_dim 1024, v_class 33, batch 10, temporal 10 (opts.py:28,61,65; ctc_exe.py:14).  Stored: the
+    per-frame inputs of the LSTMCell (self.v(feat[time])), its parameters, the initial state and v_series."""
+    import types
+    from LSTM import LSTM_cell
+    torch.manual_seed(7)
+    args = types.SimpleNamespace(extract_feat_dim=1024, v_class=33, batch_size=10, temporal=10)
+    model = LSTM_cell(args).eval()
+    with torch.no_grad():
+        model.v.layers[1].running_mean.normal_(0.0, 0.3)      # (BatchNorm statistics of a trained head, not 0 / 1)
+        model.v.layers[1].running_var.uniform_(0.5, 1.5)
+        feat = torch.randn(args.temporal, args.batch_size, 1024)
+        h0, c0 = 0.1 * torch.randn(args.batch_size, 33), 0.1 * torch.randn(args.batch_size, 33)
+        v_series = model(feat, h0, c0)
+        v_in = torch.stack([model.v(feat[t]) for t in range(args.temporal)])
+        # the final state: the module returns only v_series; redo the loop with the module's own cell
+        h, c = h0, c0
+        for t in range(args.temporal):
+            h, c = model.v_cell(v_in[t], (h, c))
+    assert torch.equal(h, v_series[-1])
+    cell = model.v_cell
+    save("lstm_series", v_in=v_in.numpy(), h0=h0.numpy(), c0=c0.numpy(), w_ih=cell.weight_ih.detach().numpy(),
+         w_hh=cell.weight_hh.detach().numpy(), b_ih=cell.bias_ih.detach().numpy(), b_hh=cell.bias_hh.detach().numpy(),
+         v_series=v_series.numpy(), c_final=c.numpy(), torch_version=np.array(torch.__version__))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     if sys.argv[1:] == ["F6"]:                                # needs torch only, not the reference's modules
         F6(None, None)
         sys.exit(0)
     NB, NBB = _import_reference()
-    which = sys.argv[1:] or ["F1", "F2", "F3", "F4", "F5", "F6"]
+    which = sys.argv[1:] or ["F1", "F2", "F3", "F4", "F5", "F6", "F7"]
     for w in which:
         print(w)
         globals()[w](NB, NBB)

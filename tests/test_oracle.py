@@ -192,3 +192,14 @@ def test_dedup_targets_more_than_64_classes_raise_like_the_reference():
         ctc_numpy.dedup_multihot_targets(rows)
     out, n = ctc_numpy.dedup_multihot_targets(rows, exact_rows=True)
     assert int(n[0]) == 0
+
+
+def test_lstm_series_restatement_matches_the_reference_module(golden):
+    """LSTM.py:39-51 (the reference's own LSTM_cell, run in eval mode by make_golden.py F7): the numpy restatement of
+    the LSTMCell loop reproduces v_series and the final cell state from the stored per-frame inputs and parameters"""
+    f = golden("lstm_series")
+    for dt, tol in ((np.float64, 2e-6), (np.float32, 5e-6)):
+        series, h, c = ctc_numpy.lstm_cell_series(f["v_in"], f["h0"], f["c0"], f["w_ih"], f["w_hh"], f["b_ih"], f["b_hh"], dt)
+        assert series.shape == f["v_series"].shape == (10, 10, 33)
+        assert np.abs(series - f["v_series"]).max() < tol and np.abs(c - f["c_final"]).max() < tol
+        assert np.abs(h - f["v_series"][-1]).max() < tol
