@@ -29,6 +29,7 @@ PROTOTYPES = {
                                        _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctc_amd_scale_grad": (_int, [_vp, _vp, _sz, _vp]),
     "ctc_amd_collective_gate": (_int, [_vp, _int, _int, _vp]),
+    "ctc_amd_binary_posteriors": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "ctc_amd_lstm_cell_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp,
                                       _vp, _i64, _int, _f32, _vp]),
     "ctc_amd_dedup_multihot_targets": (_int, [_vp, _int, _int, _int, _int, _vp, _vp, _vp]),

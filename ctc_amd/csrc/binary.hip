@@ -33,6 +33,7 @@ struct BinaryParams {
     int stop;                    // diagnostics: < 0 selects the wave that stamps phase boundaries
     float loss_scale, grad_scale;
     float *nll, *loss, *grad;
+    float *gamma;                // optional [B][T][S] posteriors output (ctc_amd_binary_posteriors; pipelined kernel only)
     unsigned *counter;
 };
 
@@ -669,7 +670,7 @@ __device__ __forceinline__ void bin_store_col(float *row, unsigned voff, int j, 
     }
 }
 
-template <int CH, bool WT>
+template <int CH, bool WT, bool GAMMA = false>               // GAMMA: the posteriors-only instantiation (ctc_amd_binary_posteriors)
 __global__ __launch_bounds__(kBinThreads) void binary_pipe_kernel(BinaryParams p, int PD)
 {
     extern __shared__ float4 smem_raw[];
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_pipe_kernel(BinaryParams p
     // ---------------- the two scans ----------------
     if (w < 2) {
         __syncthreads();
-        if (w == 1 && !p.grad) return;
+        if (w == 1 && !p.grad && !GAMMA) return;
         __builtin_amdgcn_s_setprio(3);
         bool starved = false;
         if (Tb > 0) {
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_pipe_kernel(BinaryParams p
         __builtin_amdgcn_s_setprio(0);
     }
     stamp(p, 3);
-    if (!p.grad) return;
+    if (!p.grad && !GAMMA) return;
 
     // ---------------- workers, P3: gradient rows, four at a time ----------------
     //   gamma rows (wave-local LDS), then G = gamma . Y on v_mfma_f32_4x4x1 (16 blocks of 4x4, K = 1 per
@@ -990,6 +991,12 @@ __global__ __launch_bounds__(kBinThreads) void binary_pipe_kernel(BinaryParams p
                 for (int k = 0; k < 4; ++k)
                     if (tl[k] >= 0) sm.be[tl[k] * p.SP + lane] = pe[k] * (gs * __builtin_amdgcn_rcpf(sum[k]));
             }
+            if (GAMMA && lane < p.S) {                       // posteriors output: gamma_t(l), rows sum to 1
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (tl[k] >= 0)
+                        p.gamma[((int64_t)b * p.T + tl[k]) * p.S + lane] = starved ? __builtin_nanf("") : pe[k] * __builtin_amdgcn_rcpf(sum[k]);
+            }
             if (jg == 2) stamp(p, 10);
             const int ti = tl[lane & 3];
             const float *arow = ti >= 0 ? sm.be + ti * p.SP : sm.zrow;   // (an idle slot contributes a row of zeros)
@@ -1002,7 +1009,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_pipe_kernel(BinaryParams p
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < CH; ++j) fy[i][j] = yrow[i * PD + 64 * j];
-            for (int l0 = 0; l0 < L; l0 += 4) {
+            for (int l0 = 0; l0 < (GAMMA ? 0 : L); l0 += 4) {
                 const float4 fan = *reinterpret_cast<const float4 *>(arow + (l0 + 4 < p.SP ? l0 + 4 : 0));
                 float fyn[4][CH];
 #pragma unroll
@@ -1024,6 +1031,12 @@ __global__ __launch_bounds__(kBinThreads) void binary_pipe_kernel(BinaryParams p
             if (jg == 2) stamp(p, 11);
         }
         if (starved) raise_status(p.counter, kStatusBinaryStarved);
+        if constexpr (GAMMA) {                               // posteriors only: rows beyond T_b get zeros, no gradient
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tt[i] >= 0 && tl[i] < 0 && lane < p.S) p.gamma[((int64_t)b * p.T + tt[i]) * p.S + lane] = 0.f;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (tt[i] < 0) continue;                         // wave-uniform
@@ -1124,7 +1137,7 @@ extern "C" int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_
     p.SP = (S + K - 1) / K * K;
     p.CP = C | 1;                                            // odd pitch: conflict-free column walks
     p.loss_scale = loss_scale; p.grad_scale = grad_scale;
-    p.nll = nll; p.loss = loss; p.grad = grad;
+    p.nll = nll; p.loss = loss; p.grad = grad; p.gamma = nullptr;
     p.counter = static_cast<unsigned *>(workspace);
     static const int debug_stop = diag_env("CTC_AMD_DEBUG_STOP");
     static const bool binary_valu = diag_env("CTC_AMD_BINARY_VALU") != 0;
@@ -1158,5 +1171,41 @@ extern "C" int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_
         case 1: return launch<binary_fused_kernel<1>>(grid, block, smem, s, p);
         case 2: return launch<binary_fused_kernel<2>>(grid, block, smem, s, p);
         default: return launch<binary_fused_kernel<4>>(grid, block, smem, s, p);
+    }
+}
+
+
+// Per-step posteriors of the binary lattice: gamma[b,t,l] = P(label row l at step t | x, targets), the
+// quantity the loss gradient contracts with the target rows -- it falls out of the pipelined kernel's gradient phase.
+// Shapes of that kernel only (S <= 64, T <= 168, C <= 256, images within LDS); others: CTC_AMD_ERR_UNSUPPORTED_SHAPE.
+extern "C" int ctc_amd_binary_posteriors(const float *x, int64_t stride_t, int64_t stride_b, const float *y,
+                                         const int64_t *in_len, const int64_t *tgt_len, int T, int B, int C, int S,
+                                         float *nll, float *gamma, void *workspace, void *stream)
+{
+    if (!x || !y || !in_len || !tgt_len || !nll || !gamma || !workspace) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (T < 1 || B < 1 || C < 1 || S < 1) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (S > kWave || T > kPipeMaxT || C > 256) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    BinaryParams q;
+    q.x = x; q.st = stride_t; q.sb = stride_b; q.y = y;
+    q.in_len = in_len; q.tgt_len = tgt_len;
+    q.T = T; q.B = B; q.C = C; q.S = S;
+    q.SP = (S + 3) / 4 * 4;
+    q.CP = C | 1;
+    q.loss_scale = 0.f; q.grad_scale = 0.f;
+    q.nll = nll; q.grad = nullptr; q.gamma = gamma;
+    q.counter = static_cast<unsigned *>(workspace);
+    q.loss = reinterpret_cast<float *>(static_cast<char *>(workspace) + 32);   // the batch sum lands in a spare header word
+    q.stop = 0;
+    int PD = (C + 3) / 4 * 4 + 2;
+    while (PD % 32 != 2) PD += 2;
+    const size_t smem = binary_pipe_smem_bytes(T, q.SP, PD);
+    if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    const dim3 grid(B), block(kBinThreads);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch ((C + kWave - 1) / kWave) {
+        case 1: return launch<binary_pipe_kernel<1, true, true>>(grid, block, smem, s, q, PD);
+        case 2: return launch<binary_pipe_kernel<2, true, true>>(grid, block, smem, s, q, PD);
+        case 3: return launch<binary_pipe_kernel<3, true, true>>(grid, block, smem, s, q, PD);
+        default: return launch<binary_pipe_kernel<4, true, true>>(grid, block, smem, s, q, PD);
     }
 }

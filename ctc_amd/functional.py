@@ -410,6 +410,35 @@ def noblank_posteriors(logits, targets, input_lengths, target_lengths):
     return gamma, nll
 
 
+def binary_posteriors(logits, targets, input_lengths, target_lengths):
+    """Per-step posteriors of the binary (multi-hot) lattice -> (gamma[B,T,S], nll[B]): ``gamma[b,t,l]`` =
+    P(target row l at step t | logits, targets), rows sum to 1 for ``t < T_b``.  SURVEY 8(f) rank 1, the sibling of
+    ``noblank_posteriors``; shapes of the pipelined binary kernel (S <= 64, T <= 168, C <= 256)."""
+    _require_hip(logits, "logits")
+    if logits.dim() != 3 or logits.dtype != torch.float32:
+        raise ValueError("ctc_amd: logits must be float32 [T,B,C]")
+    T, B, C = logits.shape
+    dev = logits.device
+    xs = logits.detach()
+    if xs.stride(2) != 1:
+        xs = xs.contiguous()
+    if _variant_of(targets) != _lib.BINARY or targets.shape[0] != B or targets.shape[2] != C:
+        raise ValueError("ctc_amd: targets must be [B,S,C] float")
+    tg = targets.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+    S = tg.shape[1]
+    il = _lengths(input_lengths, B, "input_lengths", dev, T)
+    tl = _lengths(target_lengths, B, "target_lengths", dev, S)
+    gamma = torch.empty((B, T, S), dtype=torch.float32, device=dev)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _workspace(_lib.BINARY, T, B, C, S, dev)
+        rc = _lib.load().ctc_amd_binary_posteriors(
+            xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(), il.data_ptr(), tl.data_ptr(), T, B, C, S,
+            nll.data_ptr(), gamma.data_ptr(), ws.data_ptr(), _stream_handle(dev))
+    _lib.check(rc, "ctc_amd_binary_posteriors")
+    return gamma, nll
+
+
 def dedup_multihot_targets(rows, exact_rows=False):
     """Target construction on the device (datasets/charades_ctc_next_pred.py:646-651,663-678).
 

@@ -199,6 +199,16 @@ int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int64_t stride_
                                float *nll, float *gamma,
                                void *workspace, void *stream);
 
+/* The same for the binary lattice (NoBlankBinaryCTC): gamma[b,t,l] = P(target row l at step t | x, y) -- what the
+ * binary loss gradient contracts with the target rows.  y [B,S,C] as ctc_amd_binary_loss_grad; gamma [B,T,S], nll [B].
+ * Shapes of the pipelined binary kernel only (S <= 64, T <= 168, C <= 256, LDS images fit); others return
+ * CTC_AMD_ERR_UNSUPPORTED_SHAPE. */
+int ctc_amd_binary_posteriors(const float *x, int64_t stride_t, int64_t stride_b, const float *y,
+                              const int64_t *in_len, const int64_t *tgt_len,
+                              int T, int B, int C, int S,
+                              float *nll, float *gamma,
+                              void *workspace, void *stream);
+
 /* The producer step of the logits: one torch.nn.LSTMCell step of the reference's LSTM_cell.forward
  * (LSTM.py:39-51: `v_hsn, v_csn = self.v_cell(v, (v_hsn, v_csn)); v_series[time] = v_hsn`), fused with the write of
  * the hidden state into the logits tensor the losses read.

@@ -675,6 +675,30 @@ def test_noblank_posteriors(dev, shape):
         assert np.abs(gamma[b, :, int(L[b]):]).max(initial=0.0) == 0.0
 
 
+@pytest.mark.parametrize("shape", [(20, 4, 10, 5), (150, 8, 158, 20), (37, 5, 64, 7), (60, 2, 40, 64), (168, 3, 33, 10)])
+def test_binary_posteriors(dev, shape):
+    """SURVEY 8(f) rank 1 for the binary lattice: gamma out of the pipelined kernel's gradient phase"""
+    import ctc_amd
+    T, B, C, S = shape
+    x, y, Tb, L = synth_binary(sum(shape) + 5, T, B, C, S, var_T=True, density=0.2)
+    gamma, nll = ctc_amd.binary_posteriors(x.to(dev), y.to(dev), Tb.to(dev), L.to(dev))
+    torch.cuda.synchronize()
+    gamma, nll = np_(gamma), np_(nll)
+    ref = ctc_numpy.binary_ctc(np_(x), np_(y), np_(Tb), np_(L), np.float64)
+    assert np.abs(gamma - ref["gamma"].transpose(1, 0, 2)).max() < 2e-4      # fp32 scans: ~1e-4 relative
+    assert (np.abs(nll - ref["nll"]) <= 1e-5 * np.maximum(1.0, np.abs(ref["nll"]))).all()
+    for b in range(B):
+        assert np.abs(gamma[b, :int(Tb[b])].sum(axis=1) - 1.0).max() < 1e-5     # a distribution per live step
+        assert np.abs(gamma[b, int(Tb[b]):]).max(initial=0.0) == 0.0
+        assert np.abs(gamma[b, :, int(L[b]):]).max(initial=0.0) == 0.0
+    # the loss + gradient call on the same inputs afterwards is unaffected (same workspace)
+    r = run_hip(ctc_amd.binary_ctc_loss, x, y, Tb, L, dev)
+    assert np.abs(r["grad"] - ref["grad"]).max() < 2e-6 * max(1.0, 256.0 / B)
+    with pytest.raises(ctc_amd.CtcAmdError):                  # beyond the pipelined kernel: says so
+        ctc_amd.binary_posteriors(torch.zeros(200, 2, 8, device=dev), torch.zeros(2, 3, 8, device=dev),
+                                  torch.tensor([200, 200]), torch.tensor([3, 3]))
+
+
 @pytest.mark.parametrize("shape", [(2000, 2, 50, 20), (700, 3, 300, 40), (900, 2, 20, 100)])
 def test_noblank_long_sequences_use_workspace_lattice(dev, shape):
     """T x S beyond LDS: the lattice moves to the workspace (ctc_amd_workspace_bytes grows)."""
