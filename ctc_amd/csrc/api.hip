@@ -54,13 +54,19 @@ extern "C" int ctc_amd_workspace_status(void *workspace, int clear, void *stream
 
 // ---- collective gate (include/ctc_amd.h) ---------------------------------------------
 namespace ctc {
-__global__ __launch_bounds__(64) void collective_gate_kernel(const unsigned *counter, unsigned need, unsigned long long ticks)
+__global__ __launch_bounds__(64) void collective_gate_kernel(unsigned *counter, unsigned need, unsigned long long ticks)
 {
-    if (threadIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    if (lane == 0) __hip_atomic_store(counter + kGateWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // loss launches count from now on
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
-    while (__hip_atomic_load(counter + kArrivalsWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need &&
-           __builtin_amdgcn_s_memrealtime() - t0 < ticks)
+    for (;;) {
+        unsigned v = lane < 16 ? __hip_atomic_load(arrival_shard(counter, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) v += __shfl_xor(v, sh, 64);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v >= need || __builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
         __builtin_amdgcn_s_sleep(8);
+    }
 }
 }  // namespace ctc
 
@@ -70,6 +76,6 @@ extern "C" int ctc_amd_collective_gate(void *workspace, int B, int timeout_us, v
     const int cus = ctc::device_cus();
     const unsigned need = (unsigned)(cus > 0 && B > cus ? cus : B);       // one round of workgroups fills the chip
     hipLaunchKernelGGL(ctc::collective_gate_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const unsigned *>(workspace), need, (unsigned long long)timeout_us * 100ull);
+                       static_cast<unsigned *>(workspace), need, (unsigned long long)timeout_us * 100ull);
     return (int)hipGetLastError();
 }

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_fused_kernel(BinaryParams 
     extern __shared__ float4 smem_raw[];
     const BinarySmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.S, p.CP);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    if (tid == 64) note_arrival(p.counter);                  // (arrivals word, common.hpp)
+    if (tid == 64) note_arrival(p.counter, b);                  // (arrivals word, common.hpp)
     const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
     const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
     const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_mfma_kernel(BinaryParams p
     extern __shared__ float4 smem_raw[];
     const BinaryMfmaSmem sm(reinterpret_cast<float *>(smem_raw), p.T, Tpad, p.SP, PD);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    if (tid == 64) note_arrival(p.counter);                  // (arrivals word, common.hpp)
+    if (tid == 64) note_arrival(p.counter, b);                  // (arrivals word, common.hpp)
     stamp(p, 0);
     const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
 
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_pipe_kernel(BinaryParams p
     extern __shared__ float4 smem_raw[];
     const BinaryPipeSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, PD);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    if (tid == 64) note_arrival(p.counter);                  // (wave 1: the beta' scan, no other vector-memory operation)
+    if (tid == 64) note_arrival(p.counter, b);                  // (wave 1: the beta' scan, no other vector-memory operation)
     typedef const volatile __attribute__((address_space(3))) int lds_cvint;
     stamp(p, 0);
     const ScalarLengths lens(p.in_len + b, p.tgt_len + b);

@@ -81,16 +81,30 @@ __device__ __forceinline__ void raise_status(unsigned *counter, unsigned bit)
     if (lane_id() == 0) __hip_atomic_fetch_or(counter + 2, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Workspace word 10 (bytes [40,44)): ARRIVALS -- how many workgroups of the launch in flight have started.  One
-// no-return atomic per workgroup at entry, issued by a wave that has no other vector-memory operation to wait
-// for (a chain / scan wave); the workgroup that completes the batch sum (the last to finish, so every workgroup
-// has arrived) puts the word back to 0.  Read by ctc_amd_collective_gate (api.hip): a collective that would
-// otherwise be dispatched BEFORE this launch and take whole CUs away from it is held
-// back until the launch has filled the chip.
-constexpr int kArrivalsWord = 10;
-__device__ __forceinline__ void note_arrival(unsigned *counter)
+// ARRIVALS -- how many workgroups of the launch in flight have started: read by ctc_amd_collective_gate (api.hip), which
+// holds a collective back until the loss launch has filled the chip.  Counting is OFF until a gate
+// has been used on the workspace (word 11, bytes [44,48): set by the gate kernel, read here through the scalar cache): one
+// atomic per workgroup on ONE word at kernel entry -- 256 of them at once, served at ~90 per us by the memory side -- delays
+// every workgroup's first row loads (measured at config 2: 12.3 -> 13.9 us per launch).  When on, the count is sharded
+// like the batch sum (sample b adds to the free upper half of shard slot b % 16: bytes [256 + 16 s + 8, +4)), issued by a
+// wave that has no other vector-memory operation to wait for (a chain / scan wave); the workgroup that completes the
+// batch sum (the last to finish, so every workgroup has arrived) puts the sixteen words back to 0.
+constexpr int kGateWord = 11;
+__device__ __forceinline__ unsigned *arrival_shard(unsigned *counter, int sh) { return counter + 64 + 4 * sh + 2; }
+__device__ __forceinline__ bool gate_on(const unsigned *counter)
 {
-    __hip_atomic_fetch_add(counter + kArrivalsWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    typedef const __attribute__((address_space(4))) unsigned const_u32;
+    return *(const_u32 *)(uintptr_t)(counter + kGateWord) != 0;
+}
+__device__ __forceinline__ void note_arrival(unsigned *counter, int b)
+{
+    if (!gate_on(counter)) return;                           // (wave-uniform: a scalar load)
+    __hip_atomic_fetch_add(arrival_shard(counter, b & 15), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void reset_arrivals(unsigned *counter)
+{
+    if (!gate_on(counter)) return;
+    for (int sh = 0; sh < 16; ++sh) __hip_atomic_store(arrival_shard(counter, sh), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Diagnostics (phase stamps, early exits) compile to nothing in the product library.
@@ -348,7 +362,7 @@ __device__ __forceinline__ void ticket_and_reduce(int B, float *nll, float *loss
     if (lane_id() == 0) {
         loss[0] = s * loss_scale;
         __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(counter + kArrivalsWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reset_arrivals(counter);
     }
 }
 template <typename F>
@@ -429,7 +443,7 @@ __device__ __forceinline__ void publish_and_reduce_sum(float value, int b, int B
         s += (double)__hip_atomic_load(&nll[bb < (unsigned)B ? bb : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     loss[0] = (float)(s * (double)loss_scale);
-    __hip_atomic_store(counter + kArrivalsWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    reset_arrivals(counter);
     __hip_atomic_store(top, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(nlist, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

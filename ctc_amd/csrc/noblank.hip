@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
 {
     extern __shared__ float4 smem_raw[];
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id();
-    if (tid == kThreads - 64) note_arrival(p.counter);       // (the last wave: its first wait is the workgroup barrier)
+    if (tid == kThreads - 64) note_arrival(p.counter, b);       // (the last wave: its first wait is the workgroup barrier)
     const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C,
                          GLB ? p.lattice + (int64_t)b * p.slab : nullptr);
     constexpr int CHR = CH > 0 ? CH : 1;

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kThreads, DUAL ? 8 : 4) void noblank_pipelined_kern
     extern __shared__ float4 smem_raw[];
     const NoblankSmem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, p.C);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    if (tid == 64 * kChainB) note_arrival(p.counter);        // (the beta chain wave has no other vector-memory operation)
+    if (tid == 64 * kChainB) note_arrival(p.counter, b);        // (the beta chain wave has no other vector-memory operation)
     // roles: waves 0 and kChainB are the chains, the rest are workers 0..13
     const int u = (w == 0 || w == kChainB) ? -1 : (w < kChainB ? w - 1 : w - 2);
     const float ninf = -__builtin_inff();

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     constexpr int G = kPipeRows / 4;                         // groups of four rows per worker
     const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, RP);
     const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    if (tid == 64 * kChainB) note_arrival(p.counter);        // (the beta chain wave has no other vector-memory operation)
+    if (tid == 64 * kChainB) note_arrival(p.counter, b);        // (the beta chain wave has no other vector-memory operation)
     const int u = (w == 0 || w == kChainB) ? -1 : (w < kChainB ? w - 1 : w - 2);
     const int rho = lane >> 4, i16 = lane & 15;              // row of the group, position inside the row
     const float ninf = -__builtin_inff();

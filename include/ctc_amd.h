@@ -16,7 +16,7 @@
  *  - the caller owns all memory.  `workspace` must hold ctc_amd_workspace_bytes(...)
  *    bytes, be zero-filled ONCE when allocated, and not be shared by launches that
  *    may run concurrently (one workspace per stream); bytes [8,12) are the status word
- *    (ctc_amd_workspace_status), bytes [40,44) the arrivals word (ctc_amd_collective_gate);
+ *    (ctc_amd_workspace_status), bytes [44,48) the gate word (ctc_amd_collective_gate);
  *  - return value: 0 on success, a hipError_t (> 0) from the launch, or one of the
  *    negative CTC_AMD_ERR_* codes; ctc_amd_error_string() describes any of them.
  */
@@ -149,9 +149,12 @@ int ctc_amd_workspace_status(void *workspace, int clear, void *stream, unsigned 
  * collective workgroup; dispatched after the launch has filled the chip it costs nothing).  Enqueue this on the
  * stream the collective will be ordered behind, AFTER the previous loss launch and BEFORE the collective: a
  * one-wave kernel that returns once min(B, #CUs) workgroups of the loss launch that uses `workspace` have
- * started (every no-blank / binary workgroup counts itself in workspace word 10 at entry, the launch's last
- * workgroup puts the word back to 0), or after timeout_us (bounded: never gate a collective that no loss
- * launch follows).  The blank-CTC launches do not count arrivals (a collective is short against them). */
+ * started, or after timeout_us (bounded: never gate a collective that no loss launch follows).  Counting is
+ * switched on by the first gate used on a workspace (the loss launches of a workspace that never saw a gate pay
+ * nothing for it; the launch right after the first gate is not counted yet and that gate runs into its bound):
+ * every no-blank / binary workgroup then counts itself at entry in sixteen sharded words of the workspace, the
+ * launch's last workgroup puts them back to 0.  The blank-CTC launches do not count (a collective is short against
+ * them). */
 int ctc_amd_collective_gate(void *workspace, int B, int timeout_us, void *stream);
 
 /* backward of the autograd.Function: grad[i] *= *grad_out (a device scalar, the

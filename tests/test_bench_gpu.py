@@ -54,9 +54,10 @@ def test_bench_collective_path_rehearsal():
     assert math.isfinite(e["value"]) and e["value"] > 1e5
 
 
-def test_collective_gate_returns_and_arrivals_word_resets():
-    """ctc_amd_collective_gate: returns at once when nothing needs holding back (B below the chip), within its
-    bound when no loss launch follows, and the launch's last workgroup puts the arrivals word back to 0."""
+def test_collective_gate_returns_and_arrival_words_reset():
+    """ctc_amd_collective_gate: the first gate on a workspace switches the counting of arrivals on; a later gate
+    opens when the next loss launch has filled the chip and runs into its bound when none follows; the launch's last
+    workgroup puts the sixteen arrival words back to 0."""
     import time
     import torch
     import ctc_amd
@@ -66,25 +67,33 @@ def test_collective_gate_returns_and_arrivals_word_resets():
     x, lab, Tb, L = synth_noblank(0, 150, 256, 158, 20)
     args = (x.to(dev).requires_grad_(True), lab.to(dev), Tb.to(dev), L.to(dev))
     assert F.collective_gate("noblank", 256, dev, launch_stream=123456789) is False      # no such stream's workspace
-    loss = ctc_amd.CTCLoss.apply(*args)
+    ctc_amd.CTCLoss.apply(*args)
     torch.cuda.synchronize()
     key = (dev.index, F._stream_handle(dev), 0)
     ws = F._workspaces[key][-1]
-    assert int(ws[40:44].view(torch.int32).item()) == 0                                 # reset by the last workgroup
+    words = ws[:512].view(torch.int32)
+
+    def arrivals():
+        return int(sum(int(words[64 + 4 * sh + 2]) for sh in range(16)))
+    assert int(words[11]) == 0 and arrivals() == 0                                      # counting is off until a gate is used
     side = torch.cuda.Stream(dev)
     main = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        assert F.collective_gate("noblank", 256, dev, launch_stream=main.cuda_stream, timeout_us=10)   # switches it on
+    torch.cuda.synchronize()
+    assert int(words[11]) == 1
     for follow in (True, False):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.cuda.stream(side):
             assert F.collective_gate("noblank", 256, dev, launch_stream=main.cuda_stream, timeout_us=20000)
         if follow:
-            loss = ctc_amd.CTCLoss.apply(*args)                                          # fills the chip: the gate opens
+            ctc_amd.CTCLoss.apply(*args)                                                 # fills the chip: the gate opens
         side.synchronize()
         el = time.perf_counter() - t0
         assert (el < 0.015) if follow else (0.015 < el < 0.2), (follow, el)             # opened by the launch / by its bound
-    torch.cuda.synchronize()
-    assert int(ws[40:44].view(torch.int32).item()) == 0
+        torch.cuda.synchronize()
+        assert arrivals() == 0                                                          # reset by the last workgroup
     assert ctc_amd.workspace_status() == 0
 
 
