@@ -82,6 +82,20 @@ def build_fault(verbose=False):
     return build(force=True, verbose=verbose, extra_flags=("-DCTC_AMD_FAULT_INJECT",), name="fault")
 
 
+def build_occupant():
+    """tools/micro/coresident.hip -> lib/libcoresident.so: the stand-in for RCCL's collective kernel that the co-residence
+    measurement (tools/coresident.py, tests/test_bench_gpu.py, `bench.py --rehearse-collective`) launches beside the loss
+    kernel.  Diagnostics only -- not linked into and not loaded by the product library."""
+    src = os.path.join(HERE, "..", "tools", "micro", "coresident.hip")
+    so = os.path.join(LIBDIR, "libcoresident.so")
+    if os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src):
+        return so
+    os.makedirs(LIBDIR, exist_ok=True)
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", src, "-o", so + ".tmp"])
+    os.replace(so + ".tmp", so)
+    return so
+
+
 if __name__ == "__main__":
     if "--diag" in sys.argv:
         print(build_diag(verbose=True))

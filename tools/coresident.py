@@ -26,11 +26,8 @@ import bench  # noqa: E402
 
 
 def load_occupant():
-    so = os.path.join(ROOT, "ctc_amd", "lib", "libcoresident.so")
-    if not os.path.exists(so):
-        import subprocess
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC",
-                               os.path.join(ROOT, "tools", "micro", "coresident.hip"), "-o", so])
+    from ctc_amd import build
+    so = build.build_occupant()           # prebuilt by __graft_entry__.build(); compiled here only if missing / stale
     lib = ctypes.CDLL(so)
     lib.coresident_launch.restype = ctypes.c_int
     lib.coresident_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
