@@ -205,6 +205,11 @@ def torch_cpu_ctc_baseline(wl, budget_s):
             "what": "torch.nn.functional.ctc_loss fwd+bwd on CPU, %d steps of the same batch" % n}
 
 
+def _host_ext_loaded():
+    from ctc_amd import functional as F
+    return F._host_ext not in (False, None)
+
+
 def eager_python_step(wl, iters=300):
     """The step through the Python surface, issued eagerly as the reference's loop does
     (train.py:427,444): CTCLoss.apply / blank_ctc_loss + loss.backward()."""
@@ -566,7 +571,9 @@ def main():
                                    "what": "CTCLoss.apply(...) + loss.backward() issued eagerly (train.py:427,444), host-inclusive",
                                    "torch_floor_us": round(floor_us, 2),
                                    "torch_floor_what": "x.sum().backward() on the same tensor, same loop: the autograd engine's own cost per eager step",
-                                   "forward_only_us": round(fwd_us, 2)}
+                                   "forward_only_us": round(fwd_us, 2),
+                                   "autograd_node": "C++ (ctc_amd/csrc/autograd_ext.cpp)" if (variant != "blank" and _host_ext_loaded())
+                                   else "python (ctc_amd/functional.py)"}
     if coll:
         if world > 1:
             dist.barrier()

@@ -293,6 +293,74 @@ class _LossFn(torch.autograd.Function):
         return _scaled_grad(ctx, gout), None, None, None, None, None, None, None
 
 
+_host_ext = False          # the C++ autograd Function (csrc/autograd_ext.cpp): False = not looked for yet, None = absent
+
+
+def _load_host_ext():
+    """ctc_amd/lib/ext/ctc_amd_autograd_ext.so, built by ctc_amd.build.build_host_ext().  It only shortens the HOST side
+    of an eager step (the same C-ABI calls from a C++ autograd node): absent or CTC_AMD_HOST_EXT=0 -> the Python
+    Functions below do the same launches."""
+    global _host_ext
+    _host_ext = None
+    if os.environ.get("CTC_AMD_HOST_EXT", "1") == "0":
+        return None
+    import ctypes
+    import importlib.util
+    from .build import HOST_EXT_SO
+    if not os.path.exists(HOST_EXT_SO):
+        return None
+    spec = importlib.util.spec_from_file_location("ctc_amd_autograd_ext", HOST_EXT_SO)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = _lib.load()
+    addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value
+    mod.set_abi(addr(lib.ctc_amd_noblank_loss_grad), addr(lib.ctc_amd_binary_loss_grad), addr(lib.ctc_amd_scale_grad))
+    _host_ext = mod
+    return mod
+
+
+def _fast_apply(x, targets, in_len, tgt_len, batch_total, variant=None):
+    """-> [loss, nll] through the C++ autograd node when every argument is already in the form the launch takes
+    (float32 logits on the current HIP device with unit stride over the classes, targets and int64 lengths contiguous
+    on that device), else None: the Python Function converts, validates and raises."""
+    ext = _host_ext
+    if ext is False:
+        ext = _load_host_ext()
+    if ext is None or _VALIDATE:
+        return None
+    T = torch.Tensor
+    if not (x.__class__ is T and targets.__class__ is T and in_len.__class__ is T and tgt_len.__class__ is T):
+        return None
+    if not x.is_cuda or x.dtype is not torch.float32 or x.dim() != 3 or x.stride(2) != 1:
+        return None
+    dev = x.device
+    Tn, B, C = x.shape
+    tdim, tdt = targets.dim(), targets.dtype
+    if tdim == 2 and (tdt is torch.int32 or tdt is torch.int64):
+        v = _lib.NOBLANK
+    elif tdim == 3 and tdt is torch.float32 and targets.shape[2] == C:
+        v = _lib.BINARY
+    else:
+        return None
+    if variant is not None and v != variant:
+        return None
+    S = targets.shape[1]
+    if (Tn < 1 or B < 1 or C < 1 or S < 1 or targets.shape[0] != B or targets.device != dev or not targets.is_contiguous()
+            or in_len.dtype is not torch.int64 or tgt_len.dtype is not torch.int64 or in_len.device != dev
+            or tgt_len.device != dev or in_len.dim() != 1 or tgt_len.dim() != 1 or in_len.shape[0] != B
+            or tgt_len.shape[0] != B or not in_len.is_contiguous() or not tgt_len.is_contiguous()
+            or torch.cuda.current_device() != dev.index or targets.requires_grad):
+        return None
+    stream = _stream_handle(dev)
+    ws = _workspace(v, Tn, B, C, S, dev, stream)
+    try:
+        return ext.ctc_loss(x, targets, in_len, tgt_len, v, 0 if batch_total is None else int(batch_total), stream, ws.data_ptr())
+    except RuntimeError as e:
+        if "ctc_amd: fused launch failed" in str(e):
+            return None                      # the Python Function repeats the call and raises the library's own error
+        raise
+
+
 class CTCLoss(torch.autograd.Function):
     """Drop-in ``CTCLoss.apply(log_probs, targets, input_lengths, target_lengths)``.
 
@@ -300,7 +368,17 @@ class CTCLoss(torch.autograd.Function):
     (NoBlankCTC.py:129-141), [B,S,C] float -> NoBlankBinaryCTC (NoBlankBinaryCTC.py:139-151).
     Optional 5th argument ``batch_total``: global batch size when this call sees only a
     shard (loss and gradient are scaled by 1/batch_total; see ctc_amd.distributed).
+
+    ``apply`` hands canonical arguments to the C++ autograd node of csrc/autograd_ext.cpp (same launches, less host
+    time per eager step); anything else -- and every error -- takes the Python Function below.
     """
+
+    @classmethod
+    def apply(cls, log_probs, targets, input_lengths, target_lengths, batch_total=None):
+        out = _fast_apply(log_probs, targets, input_lengths, target_lengths, batch_total)
+        if out is not None:
+            return out[0]
+        return super().apply(log_probs, targets, input_lengths, target_lengths, batch_total)
 
     @staticmethod
     def forward(ctx, log_probs, targets, input_lengths, target_lengths, batch_total=None):
@@ -326,12 +404,19 @@ def noblank_ctc_loss(logits, targets, input_lengths, target_lengths, batch_total
 
     ``label_smoothing=lam`` selects the emission variant sketched in comments at NoBlankCTC.py:100-107 (the
     true class weighted lam, every other class (1 - lam) / C); None = the module as shipped."""
+    if label_smoothing is None:
+        out = _fast_apply(logits, targets, input_lengths, target_lengths, batch_total, _lib.NOBLANK)
+        if out is not None:
+            return out[0], out[1]
     return _LossFn.apply(logits, targets, input_lengths, target_lengths, _lib.NOBLANK, batch_total, 0,
                          label_smoothing)
 
 
 def binary_ctc_loss(logits, targets, input_lengths, target_lengths, batch_total=None):
     """-> (loss, nll[B]); NoBlankBinaryCTC arithmetic."""
+    out = _fast_apply(logits, targets, input_lengths, target_lengths, batch_total, _lib.BINARY)
+    if out is not None:
+        return out[0], out[1]
     return _LossFn.apply(logits, targets, input_lengths, target_lengths, _lib.BINARY, batch_total, 0)
 
 
