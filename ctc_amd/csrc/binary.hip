@@ -1097,6 +1097,8 @@ static int launch_binary_pipe(int ch, size_t smem, hipStream_t s, const BinaryPa
     return wt ? launch_binary_pipe_wt<true>(ch, smem, s, p, PD) : launch_binary_pipe_wt<false>(ch, smem, s, p, PD);
 }
 
+#include "binary_flow.hpp"
+
 template <int K>
 static int launch_binary_mfma(int ch, size_t smem, hipStream_t s, const BinaryParams &p, int Tpad, int PD)
 {
@@ -1154,6 +1156,12 @@ extern "C" int ctc_amd_binary_loss_grad(const float *x, int64_t stride_t, int64_
         const size_t need = binary_mfma_smem_bytes(T, Tpad, q.SP, PD);
         const int ch = (C + kWave - 1) / kWave;
         static const bool no_pipe = diag_env("CTC_AMD_BINARY_NOPIPE") != 0;
+        static const bool no_flow = diag_env("CTC_AMD_BINARY_NOFLOW") != 0;
+        if (K == 1 && !no_pipe && !no_flow && T <= kFlowMaxT && ch <= 3) {   // (four column chunks: 4 registers over the budget)   // the streamed kernel (binary_flow.hpp) has its own image pitch
+            const int PF = binary_flow_pitch(C);
+            const size_t fb = binary_flow_smem_bytes(T, q.SP, PF, C);
+            if (fb <= kMaxLds) return launch_binary_flow(ch, fb, s, q, PF);
+        }
         if (K == 1 && !no_pipe && binary_pipe_smem_bytes(T, q.SP, PD) <= kMaxLds)
             return launch_binary_pipe(ch, binary_pipe_smem_bytes(T, q.SP, PD), s, q, PD);
         if (need <= kMaxLds && T <= kBinRows * kBinWaves) {

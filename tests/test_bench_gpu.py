@@ -109,4 +109,4 @@ def test_resident_collective_kernel_costs_a_round_unless_the_launch_came_first()
     assert d["collective first"]["k=1"] > base + 4.0, d
     for order in ("loss first", "gated"):
         for k in ("k=1", "k=2", "k=8"):
-            assert d[order][k] < base + 1.5, (order, k, d)
+            assert d[order][k] < base + 3.0, (order, k, d)    # (a second round costs 8 us; single medians wobble by 1-2)
