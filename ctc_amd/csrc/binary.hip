@@ -583,7 +583,8 @@ static size_t binary_pipe_smem_bytes(int T, int SP, int PD)
 
 // lattice_chain<1> fed tile by tile: `ready(i)` returns once the emission rows of every step <= i are in LDS
 // (steps count from the scan's own end of the sequence)
-template <bool FWD, bool ROT, typename Ready>
+// LOG2: the lattice in units of log2 (emissions arrive multiplied by log2 e): a step is two multiplications shorter
+template <bool FWD, bool ROT, bool LOG2 = false, typename Ready>
 __device__ __forceinline__ void lattice_chain_fed(const float *em, float *out, float *dummy, int Tb, int L, int SP,
                                                   int *prog, Ready &&ready)
 {
@@ -604,8 +605,13 @@ __device__ __forceinline__ void lattice_chain_fed(const float *em, float *out, f
         } else {
             adv = FWD ? wave_shr1(a, kNeg) : wave_shl1(a, kNeg);
         }
-        const float t = __builtin_amdgcn_exp2f(-fabsf(a - adv) * kLog2e);
-        a = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + t), kLn2, vmax(a, adv)) + e;
+        if (LOG2) {
+            const float t = __builtin_amdgcn_exp2f(-fabsf(a - adv));
+            a = (__builtin_amdgcn_logf(1.0f + t) + vmax(a, adv)) + e;
+        } else {
+            const float t = __builtin_amdgcn_exp2f(-fabsf(a - adv) * kLog2e);
+            a = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + t), kLn2, vmax(a, adv)) + e;
+        }
         *wr = a;
         wr += winc;
     };
@@ -1204,13 +1210,19 @@ extern "C" int ctc_amd_binary_posteriors(const float *x, int64_t stride_t, int64
     q.counter = static_cast<unsigned *>(workspace);
     q.loss = reinterpret_cast<float *>(static_cast<char *>(workspace) + 32);   // the batch sum lands in a spare header word
     q.stop = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int ch = (C + kWave - 1) / kWave;
+    if (T <= kFlowMaxT && ch <= 3) {                          // the streamed kernel, cut off after the posteriors
+        const int PF = binary_flow_pitch(C);
+        const size_t fb = binary_flow_smem_bytes(T, q.SP, PF, C);
+        if (fb <= kMaxLds) return launch_binary_flow_wt<true, true>(ch, fb, s, q, PF);
+    }
     int PD = (C + 3) / 4 * 4 + 2;
     while (PD % 32 != 2) PD += 2;
     const size_t smem = binary_pipe_smem_bytes(T, q.SP, PD);
     if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
     const dim3 grid(B), block(kBinThreads);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch ((C + kWave - 1) / kWave) {
+    switch (ch) {
         case 1: return launch<binary_pipe_kernel<1, true, true>>(grid, block, smem, s, q, PD);
         case 2: return launch<binary_pipe_kernel<2, true, true>>(grid, block, smem, s, q, PD);
         case 3: return launch<binary_pipe_kernel<3, true, true>>(grid, block, smem, s, q, PD);

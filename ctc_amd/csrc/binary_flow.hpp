@@ -223,6 +223,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
     const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
     const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
     const float invC = 1.0f / (float)p.C;
+    const float inv2 = invC * kLog2e;                        // emissions, alpha and beta' are kept in units of log2
     const float gs = p.grad_scale * invC;
     stamp(p, 1);
 
@@ -248,11 +249,11 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             };
             const bool rot = p.SP <= 63;
             if (w == 0) {
-                if (rot) lattice_chain_fed<true, true>(sm.em, sm.al, sm.dummy, Tb, L, p.SP, sm.prog, ready);
-                else lattice_chain_fed<true, false>(sm.em, sm.al, sm.dummy, Tb, L, p.SP, sm.prog, ready);
+                if (rot) lattice_chain_fed<true, true, true>(sm.em, sm.al, sm.dummy, Tb, L, p.SP, sm.prog, ready);
+                else lattice_chain_fed<true, false, true>(sm.em, sm.al, sm.dummy, Tb, L, p.SP, sm.prog, ready);
             } else {
-                if (rot) lattice_chain_fed<false, true>(sm.em, sm.be, sm.dummy, Tb, L, p.SP, sm.prog + 1, ready);
-                else lattice_chain_fed<false, false>(sm.em, sm.be, sm.dummy, Tb, L, p.SP, sm.prog + 1, ready);
+                if (rot) lattice_chain_fed<false, true, true>(sm.em, sm.be, sm.dummy, Tb, L, p.SP, sm.prog + 1, ready);
+                else lattice_chain_fed<false, false, true>(sm.em, sm.be, sm.dummy, Tb, L, p.SP, sm.prog + 1, ready);
             }
             if (starved) {                                   // let the workers through; they poison their rows
                 *sm.fail = 1;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
         __builtin_amdgcn_s_setprio(0);
         stamp(p, 5);
         if (w == 0) {
-            float nll = ok ? -sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;
+            float nll = ok ? -kLn2 * sm.al[(Tb - 1) * p.SP + (L - 1)] : -kNeg;   // (the lattice is in units of log2)
             if (starved || *(lds_cvint *)sm.fail) {          // a bounded wait ran out: NaN, not a plausible number
                 nll = __builtin_nanf("");
                 raise_status(p.counter, kStatusBinaryStarved);
@@ -302,15 +303,18 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             stamp(p, nt == 0 ? 8 : nt == 1 ? 4 : 6);
             const int ta = 16 * m + fr;
             const float *arow = sm.dimg + (ta < p.T ? ta : p.T - 1) * PD;
-            auto epilogue = [&](auto N, const f32x4 *acc) {
+            auto epilogue = [&](auto N, const f32x4 *acc) {    // branch-free: lanes outside the tile store into an idle slot
                 constexpr int NN = decltype(N)::value;
+                const float4 q4 = *reinterpret_cast<const float4 *>(sm.q + 16 * m + 4 * fq);
+                const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
                 for (int n = 0; n < NN; ++n) {
                     const int lrow = 16 * n + fr;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int t = 16 * m + 4 * fq + i;
-                        if (t < Tb && lrow < p.SP) sm.em[t * p.SP + lrow] = lrow < L ? (acc[n][i] + sm.q[t]) * invC : kNeg;
+                        float *dst = (t < Tb && lrow < p.SP) ? sm.em + t * p.SP + lrow : sm.dummy + i;
+                        *dst = lrow < L ? (acc[n][i] + qv[i]) * inv2 : kNeg;
                     }
                 }
             };
@@ -415,13 +419,13 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
 #pragma unroll
     for (int g = 0; g < kFlowRounds; ++g) {
         if (g < NG) {                                        // (uniform)
+            float ql[2];
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const int t = slot_row(g, side);
                 float far = 0.f;                             // max_j |x_j + 5|: < 11 <=> every x_j in (-16, 6)
 #pragma unroll
                 for (int j = 0; j < CH; ++j) far = fmaxf(far, fabsf(v[g][side][j] + 5.0f));
-                float ql;
                 if (__builtin_amdgcn_ballot_w64(!(far < 11.0f)) != 0) slow |= 1u << (2 * g + side);
                 if (!((slow >> (2 * g + side)) & 1)) {
                     float prod = 1.0f, sx = 0.f;
@@ -436,9 +440,9 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
                         sx += in ? xv : 0.f;
                         if (t >= 0 && (j < CH - 1 || c < PD)) sm.dimg[t * PD + c] = in ? xv : 0.f;   // zero K padding
                     }
-                    ql = __builtin_fmaf(__builtin_amdgcn_logf(prod), -kLn2, -sx);
+                    ql[side] = __builtin_fmaf(__builtin_amdgcn_logf(prod), -kLn2, -sx);
                 } else {
-                    ql = 0.f;
+                    ql[side] = 0.f;
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
                         const int c = lane + 64 * j;
@@ -446,12 +450,16 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
                         bce_logs_fast_s(v[g][side][j], sv, lp, lq);
                         v[g][side][j] = sv;
                         const bool in = j < CH - 1 || c < p.C;
-                        ql += in ? lq : 0.f;
+                        ql[side] += in ? lq : 0.f;
                         if (t >= 0 && (j < CH - 1 || c < PD)) sm.dimg[t * PD + c] = in ? lp - lq : 0.f;
                     }
                 }
-                ql = wave_sum(ql);
-                if (lane == 0 && t >= 0) sm.q[t] = ql;
+            }
+            wave_sum2(ql[0], ql[1]);                         // (both rows of the round in one pass of DPP steps)
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int t = slot_row(g, side);
+                if (lane == 0 && t >= 0) sm.q[t] = ql[side];
             }
             lds_order();
             sm.done[u] = g + 1;                              // both rows of the round are in LDS (same wave: in order)
@@ -474,8 +482,16 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
     // is the lane and the four rows are the four accumulator registers -- the layout of the resident rows); then per
     // element a reciprocal, one fma and the store.
     bool starved = !wait_y();
+    // the sigmoids of the resident rows, now, while the scans are on their way to the middle of the sequence
+#pragma unroll
+    for (int g = 0; g < kFlowRounds; ++g)
+        if (g < NG)
+#pragma unroll
+            for (int side = 0; side < 2; ++side)
+#pragma unroll
+                for (int j = 0; j < CH; ++j) v[g][side][j] = __builtin_amdgcn_rcpf(v[g][side][j]);
     bool have_lse = false;
-    float c2 = 0.f;                                          // -lse * log2(e)
+    float c2 = 0.f;                                          // -(log2 of the rows' normaliser)
     const unsigned voff = 4u * lane;
     const int lane_l = lane < p.SP ? lane : 0;
     const bool in_l = lane < L;
@@ -521,17 +537,17 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             float m[4] = {z[0], z[1], z[2], z[3]};
             wave_max4(m[0], m[1], m[2], m[3]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pe[k] = __builtin_amdgcn_exp2f((z[k] - (tl[k] >= 0 ? m[k] : 0.f)) * kLog2e);
+            for (int k = 0; k < 4; ++k) pe[k] = __builtin_amdgcn_exp2f(z[k] - (tl[k] >= 0 ? m[k] : 0.f));
 #pragma unroll
             for (int k = 0; k < 4; ++k) sum[k] = pe[k];
             wave_sum4(sum[0], sum[1], sum[2], sum[3]);
 #pragma unroll
             for (int k = 3; k >= 0; --k)
-                if (tl[k] >= 0) c2 = -kLog2e * m[k] - __builtin_amdgcn_logf(sum[k]);   // (uniform)
+                if (tl[k] >= 0) c2 = -m[k] - __builtin_amdgcn_logf(sum[k]);   // (uniform)
             have_lse = true;
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pe[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(z[k], kLog2e, c2));
+            for (int k = 0; k < 4; ++k) pe[k] = __builtin_amdgcn_exp2f(z[k] + c2);
 #pragma unroll
             for (int k = 0; k < 4; ++k) sum[k] = pe[k];
             wave_sum4(sum[0], sum[1], sum[2], sum[3]);
@@ -548,7 +564,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
                     p.gamma[((int64_t)b * p.T + tl[k]) * p.S + lane] = starved ? __builtin_nanf("") : pe[k] * __builtin_amdgcn_rcpf(sum[k]);
         }
     };
-    auto elem = [&](int jg) {
+    auto elem = [&](int jg, int vb) {                        // vb: where the group's rows sit in v[] (a constant after unrolling)
         int tt[4], tl[4], t_hi, t_lo;
         rows_of(jg, tt, tl, t_hi, t_lo);
         if (starved) raise_status(p.counter, kStatusBinaryStarved);
@@ -607,7 +623,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             } else if ((slow >> slot) & 1) {                 // (uniform) a row with tails: torch's floored denominator
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    const float pr = __builtin_amdgcn_rcpf(v[GA + (i & 1)][i >> 1][j]);
+                    const float pr = v[vb + (i & 1)][i >> 1][j];
                     const float pq = pr * (1.0f - pr);
                     const float gv = __builtin_fmaf(pr, gs, -acc[j][i]) * (pq * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f)));
                     if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, gv);
@@ -615,7 +631,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             } else {
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    const float pr = __builtin_amdgcn_rcpf(v[GA + (i & 1)][i >> 1][j]);
+                    const float pr = v[vb + (i & 1)][i >> 1][j];
                     if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, __builtin_fmaf(pr, gs, -acc[j][i]));
                 }
             }
@@ -630,7 +646,11 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
                 for (int j = 0; j < CH; ++j) v[r][side][j] = v[r - 2][side][j];
     };
     stamp(p, 3);
+#ifdef CTC_X_FLOW_ROTATE
 #pragma nounroll
+#else
+#pragma unroll
+#endif
     for (int jg = kFlowGroups - 1; jg >= 0; --jg) {          // rows nearest the middle are ready first
         if (jg < NGR) {                                      // (uniform)
             int spins = 0;
@@ -645,9 +665,14 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             else __builtin_amdgcn_s_setprio(0);
 #endif
             post(jg);
-            elem(jg);
+#ifdef CTC_X_FLOW_ROTATE
+            elem(jg, GA);
         }
         rotate();
+#else
+            elem(jg, 2 * jg);
+        }
+#endif
     }
     stamp(p, 7);
 }

@@ -11,7 +11,7 @@
     (defined(CTC_X_NOSTATUS) || defined(CTC_X_NOREDUCE) || defined(CTC_X_NORETURN) || defined(CTC_X_NOCHAIN) || \
      defined(CTC_X_NOPRIO) || defined(CTC_X_NOREAD) || defined(CTC_X_NOWRITE) || defined(CTC_X_FULL_LATTICE) || \
      defined(CTC_X_GATHER_ONCE) || defined(CTC_X_WMASK) || defined(CTC_X_NOPROG) || defined(CTC_X_NORENORM) || \
-     defined(CTC_X_ROWDPP) || defined(CTC_X_SCALAR_STEP) || defined(CTC_X_NO_POOL_GATHER) || defined(CTC_X_FLOW_NO_GPRIO) || \
+     defined(CTC_X_ROWDPP) || defined(CTC_X_SCALAR_STEP) || defined(CTC_X_NO_POOL_GATHER) || defined(CTC_X_FLOW_NO_GPRIO) || defined(CTC_X_FLOW_ROTATE) || \
      defined(CTC_FLOW_TILE_WAVES))
 #error "CTC_X_* experiment switches need -DCTC_AMD_EXPERIMENTS (A/B builds only, never the product library)"
 #endif
@@ -238,6 +238,16 @@ __device__ __forceinline__ void wave_sum4(float &a, float &b, float &c, float &d
     CTC_DPP2(OP, "row_half_mirror row_mask:0xf")               \
     CTC_DPP2(OP, "row_mirror row_mask:0xf")                    \
     CTC_DPP2(OP, "row_bcast:15 row_mask:0xa")
+// two whole-wave sums at once (six fused DPP steps, the two chains interleaved): 12 VALU + 2 readlanes for both,
+// against ~20 VALU per sum from the generic form above
+#define CTC_REDUCE2_WAVE(OP)                                   \
+    CTC_REDUCE2_HALVES(OP)                                     \
+    CTC_DPP2(OP, "row_bcast:31 row_mask:0xc")
+__device__ __forceinline__ void wave_sum2(float &a, float &b)
+{
+    asm volatile(CTC_REDUCE2_WAVE("v_add_f32_dpp") : "+v"(a), "+v"(b));
+    a = lane63(a); b = lane63(b);
+}
 __device__ __forceinline__ float half_pick(float v, bool upper)
 {
     const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));

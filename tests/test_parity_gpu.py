@@ -962,3 +962,22 @@ def test_batch_sum_resolution_on_tiny_losses(dev, B):
     assert abs(float(loss) - float(np_(nll).astype(np.float64).mean())) <= 2.0 ** -(frac + 1) + 1e-11
     # (the nll itself is fp32 arithmetic on T emissions of ~1 ulp each: absolute error ~1e-6 whatever its size)
     assert abs(float(loss) - float(ref["loss"])) < 5e-6
+
+
+def test_binary_streamed_kernel_target_forms_and_boundaries(dev):
+    """binary_flow.hpp: multi-hot targets and soft targets that are exact in bf16 (0.5, 0.25, 1.5) take the bf16 emission
+    tiles, other soft targets the fp32 tiles -- same shapes, all against the float64 oracle; T = 160 is the streamed
+    kernel's last length, T = 161 / C = 200 (four column chunks) go to the barrier-phased kernel."""
+    import ctc_amd
+    for case, (T, B, C, S) in enumerate([(150, 6, 158, 20), (160, 3, 158, 20), (161, 3, 158, 20), (96, 4, 200, 12), (33, 5, 17, 40)]):
+        x, y, Tb, L = synth_binary(4000 + case, T, B, C, S, var_T=True, density=0.1)
+        g = torch.Generator().manual_seed(case)
+        forms = {"multi-hot": y,
+                 "bf16-exact soft": y * torch.tensor([0.5, 0.25, 1.0, 1.5])[torch.randint(0, 4, y.shape, generator=g)],
+                 "soft": y * torch.rand(y.shape, generator=g)}
+        for name, yy in forms.items():
+            ref = ctc_c.binary_ctc(np_(x), np_(yy), np_(Tb), np_(L), np.float64)
+            r = run_hip(ctc_amd.binary_ctc_loss, x, yy, Tb, L, dev)
+            assert np.isfinite(r["grad"]).all(), (name, T, B, C, S)
+            assert (np.abs(r["nll"] - ref["nll"]) <= 3e-6 * np.maximum(1.0, np.abs(ref["nll"]))).all(), (name, T, B, C, S)
+            assert np.abs(r["grad"] - ref["grad"]).max() <= 2e-7 * max(1.0, 256.0 / B), (name, T, B, C, S)

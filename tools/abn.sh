@@ -1,5 +1,5 @@
 #!/bin/bash
-# interleaved comparison of N library builds: tools/_abn.sh lib1.so lib2.so ... -- [bench args]
+# interleaved comparison of N library builds: tools/abn.sh lib1.so lib2.so ... -- [bench args]
 LIBS=(); while [ "$1" != "--" ] && [ -n "$1" ]; do LIBS+=("$(realpath $1)"); shift; done; shift
 for round in 1 2 3; do
   for lib in "${LIBS[@]}"; do
