@@ -15,7 +15,7 @@ bash tools/profile.sh $O/prof_${R}_blank --variant blank                        
 echo "blank done"
 python tools/summarize_prof.py $O/prof_${R}_noblank     $O/sum_${R}/${R}_noblank_cfg2   noblank_B256  24268800  r16_kernel   > /dev/null
 python tools/summarize_prof.py $O/prof_${R}_noblank2048 $O/sum_${R}/${R}_noblank_B2048  noblank_B2048 194150400 r16_kernel   > /dev/null
-python tools/summarize_prof.py $O/prof_${R}_binary      $O/sum_${R}/${R}_binary_cfg3    binary_B256   24268800  binary_pipe  > /dev/null
+python tools/summarize_prof.py $O/prof_${R}_binary      $O/sum_${R}/${R}_binary_cfg3    binary_B256   24268800  binary_      > /dev/null
 python tools/summarize_prof.py $O/prof_${R}_blank       $O/sum_${R}/${R}_blank_cfg5     blank_B64     512000000 blank_       > /dev/null
 for v in noblank noblank2048 binary blank; do cp $(find $O/prof_${R}_$v/trace -name "*kernel_stats.csv" | head -1) $O/sum_${R}/${R}_${v}_kernel_stats.csv; done
 # the raw per-dispatch CSVs are large: keep the summaries, the stats and the bench lines
