@@ -522,6 +522,50 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
         rows_of(jg, tt, tl, t_hi, t_lo);
         if (t_hi < 0) return;                                // (uniform) no live row
         lds_order();
+        if (p.SP <= 32) {                                    // (uniform) two rows per register, side by side in the halves of the wave:
+            const int hl = lane & 31;                        // half as many loads, additions, exponentials and reduction steps
+            const bool up = lane >= 32;
+            const bool in_h = hl < L;
+            int tr[2];
+            float z[2], pe[2], sum[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                tr[r] = up ? tl[2 * r + 1] : tl[2 * r];
+                const int off = (tr[r] >= 0 ? tr[r] : 0) * p.SP + (hl < p.SP ? hl : 0);
+                const float za = sm.al[off], zb = sm.be[off], ze = sm.em[off];
+                z[r] = (in_h && tr[r] >= 0) ? za + zb - ze : ninf;
+            }
+            if (!have_lse) {                                 // (uniform) first group of this worker
+                float m[2] = {z[0], z[1]};
+                halves_max2(m[0], m[1], up);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) pe[r] = __builtin_amdgcn_exp2f(z[r] - (tr[r] >= 0 ? m[r] : 0.f));
+#pragma unroll
+                for (int r = 0; r < 2; ++r) sum[r] = pe[r];
+                halves_sum2(sum[0], sum[1], up);
+#pragma unroll
+                for (int k = 3; k >= 0; --k)                 // (every live row's normaliser is the same number: take one)
+                    if (tl[k] >= 0) {                        // (uniform)
+                        const float lse = -m[k >> 1] - __builtin_amdgcn_logf(sum[k >> 1]);
+                        c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lse), (k & 1) ? 32 : 0));
+                    }
+                have_lse = true;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) pe[r] = __builtin_amdgcn_exp2f(z[r] + c2);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) sum[r] = pe[r];
+                halves_sum2(sum[0], sum[1], up);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float inv = __builtin_amdgcn_rcpf(sum[r]);
+                if (hl < p.SP && tr[r] >= 0) sm.be[tr[r] * p.SP + hl] = pe[r] * (gs * inv);
+                if (GAMMA && hl < p.S && tr[r] >= 0)         // posteriors output: gamma_t(l), rows sum to 1
+                    p.gamma[((int64_t)b * p.T + tr[r]) * p.S + hl] = starved ? __builtin_nanf("") : pe[r] * inv;
+            }
+            return;
+        }
         float z[4], pe[4], sum[4];
         {   // (idle slots read row 0 and are masked: twelve loads in flight, one wait)
             float za[4], zb[4], ze[4];
