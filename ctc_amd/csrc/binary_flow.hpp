@@ -433,14 +433,22 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
                     for (int j = 0; j < CH; ++j) {
                         const int c = lane + 64 * j;
                         const float xv = v[g][side][j];
+#ifdef CTC_X_FLOW_NOEXP                                      // (ablation: are the logs bound by their arithmetic or by the rows' arrival?)
+                        const float sv = 1.0f + xv * xv;
+#else
                         const float sv = 1.0f + __builtin_amdgcn_exp2f(xv * -kLog2e);
+#endif
                         v[g][side][j] = sv;
                         const bool in = j < CH - 1 || c < p.C;          // (only the last chunk can pass C)
                         prod *= in ? sv : 1.0f;
                         sx += in ? xv : 0.f;
                         if (t >= 0 && (j < CH - 1 || c < PD)) sm.dimg[t * PD + c] = in ? xv : 0.f;   // zero K padding
                     }
+#ifdef CTC_X_FLOW_NOEXP
+                    ql[side] = prod - sx;
+#else
                     ql[side] = __builtin_fmaf(__builtin_amdgcn_logf(prod), -kLn2, -sx);
+#endif
                 } else {
                     ql[side] = 0.f;
 #pragma unroll

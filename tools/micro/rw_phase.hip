@@ -91,6 +91,27 @@ __global__ __launch_bounds__(1024) void phase_kernel(const float *x, float *g, i
     }
 }
 
+// read-only, 4-byte accesses (lane = column, three loads per row: the row layout of the binary kernels)
+template <bool XCD>
+__global__ __launch_bounds__(1024) void read_dword_kernel(const float *x, float *g, int T, int B, int C)
+{
+    constexpr int R = 10;
+    const int b = XCD ? xcd_sample(blockIdx.x, B) : blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float v[R][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = w + 16 * r;
+        if (t >= T) break;
+        const float *row = x + ((size_t)t * B + b) * C;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int c = lane + 64 * j; v[r][j] = row[c < C ? c : C - 1]; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { if (w + 16 * r >= T) break; for (int j = 0; j < 3; ++j) s += v[r][j]; }
+    if (s == 12345.678f) g[0] = s;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <int VEC, int MODE, int ST, bool XCD>
@@ -139,6 +160,23 @@ int main()
             if (run<4, 3, 2, true>("read then write 16 B write-through sc0 sc1", x, g, T, B, C, s)) return 1;
             if (run<4, 3, 3, true>("read then write 16 B sc1", x, g, T, B, C, s)) return 1;
             if (run<4, 3, 4, true>("read then write 16 B sc0", x, g, T, B, C, s)) return 1;
+            if (run<2, 1, 0, true>("read  8 B", x, g, T, B, C, s)) return 1;
+            if (run<4, 1, 0, true>("read 16 B", x, g, T, B, C, s)) return 1;
+            {
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                float best = 1e9f;
+                for (int rep = 0; rep < 5; ++rep) {
+                    CK(hipEventRecord(e0, s));
+                    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL((read_dword_kernel<true>), dim3(B), dim3(1024), 0, s, x, g, T, B, C);
+                    CK(hipEventRecord(e1, s));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (rep && ms < best) best = ms;
+                }
+                printf("%-44s C=%3d B=%4d: %6.2f us per launch (eager launches back to back)\n", "read  4 B (lane = column, 3 loads per row)", C, B, best * 1e3 / 200);
+            }
             if (run<4, 2, 0, true>("write 16 B nt", x, g, T, B, C, s)) return 1;
             if (run<4, 2, 2, true>("write 16 B write-through", x, g, T, B, C, s)) return 1;
             if (run<4, 2, 3, true>("write 16 B sc1", x, g, T, B, C, s)) return 1;
