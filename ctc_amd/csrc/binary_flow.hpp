@@ -72,7 +72,7 @@ struct BinaryFlowSmem {
         done = f + 20;                                       // [kFlowWorkers] rounds of logs worker u has published
         ystage = f + 32;                                     // [kFlowFirstWorker] that wave's share of the bf16 target images is in LDS (1: exact, 2: not)
         q = dummy + kFlowFlags;
-        zrow = q + ((T + 3) & ~3);
+        zrow = q + ((T + 7) & ~3);                            // (q[T]: where idle slots put their sum)
         ys = zrow + 64;
         y16 = reinterpret_cast<unsigned short *>(ys + (((size_t)SP * PD + 3) & ~(size_t)3));
         dimg = ys + flow_y_floats(SP, C, PD);
@@ -81,7 +81,7 @@ struct BinaryFlowSmem {
 
 static size_t binary_flow_smem_bytes(int T, int SP, int PD, int C)
 {
-    return ((size_t)(3 * T + 2 * kPrefetch) * SP + kFlowFlags + ((T + 3) & ~3) + 64 + flow_y_floats(SP, C, PD) + (size_t)T * PD) * 4;
+    return ((size_t)(3 * T + 2 * kPrefetch) * SP + kFlowFlags + ((T + 7) & ~3) + 64 + flow_y_floats(SP, C, PD) + (size_t)(T + 1) * PD) * 4;
 }
 
 // pitch of the D image (and of the fp32 target image): >= the K extent padded to 32, and = 4 (mod 32) -- the 16-byte
@@ -423,12 +423,13 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const int t = slot_row(g, side);
+                float *drow = sm.dimg + (t >= 0 ? t : p.T) * PD + lane;   // (an idle slot writes the spare row behind the image)
                 float far = 0.f;                             // max_j |x_j + 5|: < 11 <=> every x_j in (-16, 6)
 #pragma unroll
                 for (int j = 0; j < CH; ++j) far = fmaxf(far, fabsf(v[g][side][j] + 5.0f));
                 if (__builtin_amdgcn_ballot_w64(!(far < 11.0f)) != 0) slow |= 1u << (2 * g + side);
                 if (!((slow >> (2 * g + side)) & 1)) {
-                    float prod = 1.0f, sx = 0.f;
+                    float prod = 1.0f, sx = -0.f;                // (-0 + x is x for every x: the first addition folds away)
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
                         const int c = lane + 64 * j;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
                         const bool in = j < CH - 1 || c < p.C;          // (only the last chunk can pass C)
                         prod *= in ? sv : 1.0f;
                         sx += in ? xv : 0.f;
-                        if (t >= 0 && (j < CH - 1 || c < PD)) sm.dimg[t * PD + c] = in ? xv : 0.f;   // zero K padding
+                        if (j < CH - 1 || c < PD) drow[64 * j] = in ? xv : 0.f;   // zero K padding
                     }
 #ifdef CTC_X_FLOW_NOEXP
                     ql[side] = prod - sx;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
                         v[g][side][j] = sv;
                         const bool in = j < CH - 1 || c < p.C;
                         ql[side] += in ? lq : 0.f;
-                        if (t >= 0 && (j < CH - 1 || c < PD)) sm.dimg[t * PD + c] = in ? lp - lq : 0.f;
+                        if (j < CH - 1 || c < PD) drow[64 * j] = in ? lp - lq : 0.f;
                     }
                 }
             }
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const int t = slot_row(g, side);
-                if (lane == 0 && t >= 0) sm.q[t] = ql[side];
+                if (lane == 0) sm.q[t >= 0 ? t : p.T] = ql[side];
             }
             lds_order();
             sm.done[u] = g + 1;                              // both rows of the round are in LDS (same wave: in order)
