@@ -663,6 +663,20 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
                 }
             }
         }
+        // the usual group -- four live rows, none with tails -- in one piece: one uniform branch instead of a dozen
+        const unsigned slow4 = (slow >> (4 * jg)) & 15u;     // (bits 4jg .. 4jg+3: slots (2jg, 0), (2jg, 1), (2jg+1, 0), (2jg+1, 1))
+        if (!starved && slow4 == 0 && tl[0] >= 0 && tl[1] >= 0 && tl[2] >= 0 && tl[3] >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float *g = p.grad + ((int64_t)tl[i] * p.B + b) * p.C;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float pr = v[vb + (i & 1)][i >> 1][j];
+                    if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, __builtin_fmaf(pr, gs, -acc[j][i]));
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (tt[i] < 0) continue;                         // wave-uniform
