@@ -107,6 +107,8 @@ def test_resident_collective_kernel_costs_a_round_unless_the_launch_came_first()
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])["us_per_launch_event_bracketed_median"]
     base = d["loss first"]["k=0"]
     assert d["collective first"]["k=1"] > base + 4.0, d
+    second_round = min(d["collective first"][k] for k in ("k=1", "k=2", "k=8"))
     for order in ("loss first", "gated"):
-        for k in ("k=1", "k=2", "k=8"):
-            assert d[order][k] < base + 3.0, (order, k, d)    # (a second round costs 8 us; single medians wobble by 1-2)
+        for k in ("k=1", "k=2", "k=8"):                      # (a second round costs 8 us; single medians wobble by 1-3 on a busy box)
+            assert d[order][k] < second_round - 3.0, (order, k, d)
+        assert min(d[order][k] for k in ("k=1", "k=2", "k=8")) < base + 2.0, (order, d)
