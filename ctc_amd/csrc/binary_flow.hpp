@@ -1,31 +1,28 @@
-// binary_flow_kernel: the binary loss + gradient with every stage STREAMED to the next (round 3).
+// binary_flow_kernel: the binary loss + gradient with the emissions STREAMED to the scans (round 3).
 // Included by binary.hip (same arithmetic and helpers as binary_pipe_kernel; what changes is who does what, when, and on
 // which unit).
 //
 // binary_pipe_kernel runs its phases one after another for the whole sample: logs of all rows, a workgroup barrier, all
-// emission tiles, and only then do the scans start (11.5 us after entry at config 3, of 27.7); its two contractions are
-// fp32 MFMA, which the stamps show to share the SIMD's issue time with the VALU work of the other waves.  Here:
+// emission tiles, and only then do the scans start (11.5 us after entry at config 3, of 27.7); its emission tiles are fp32
+// MFMA, which takes three quarters of the SIMD's issue time away from the VALU work of the waves beside it
+// (tools/micro/mfma_rate.hip).  Here:
 //
-//   waves 0 / 1    the alpha / beta' scans, as before: one tile flag per 16 steps.
+//   waves 0 / 1    the alpha / beta' scans: one tile flag per 16 steps; the lattice is kept in units of log2.
 //   waves 2..5     TILE waves, one per SIMD, no rows of their own.  Emission tiles E = D . Y^T: (direction, parity) =
 //                  (k & 1, k >> 1) makes the front tiles k>>1, k>>1 + 2, ... or the back tiles MT-1 - (k>>1), ... up to
 //                  the middle of the sequence; a tile job starts when the owners of its 16 rows have published them.
-//                  Then the gradient's contraction G = gamma . Y, 16 rows x all classes per job, middle of the sequence
-//                  first, as the workers publish the posteriors; G goes into the (dead) rows of the D image.
 //   waves 6..15    10 workers.  Worker u owns sixteen rows: slot (g, side), g = 0..7, is the front row 10g+u or the back
 //                  row T-1-(10g+u).  Logs outside-in (the rows the scans need first), `done[u] = rounds finished` after
-//                  each pair; no barrier.  Then, per group of four rows and middle-out as both scans pass them: the
-//                  posteriors (-> LDS, `gdone[u]`), and, once the G tiles of those rows are there, the elementwise
-//                  gradient and its stores.
+//                  each pair, no barrier, priority falling as the wave advances (a SIMD serves its oldest wave first:
+//                  the youngest worker would otherwise hold every tile back).  Then the gradient, four rows at a time,
+//                  middle-out as both scans pass them: posteriors, G = gamma . Y on v_mfma_f32_4x4x1, elementwise, stores.
 //
-// Multi-hot targets are exact in bf16, so both contractions run on v_mfma_f32_16x16x32_bf16 with the fp32 operand (the
-// D row, the posterior row) split into three bf16 terms on the fly (24 significant bits = 3 x 8: the split is exact,
-// products of two bf16 are exact in fp32, accumulation is fp32): a sixteenth of the fp32 matrix time per term.  Whether a
-// sample's targets ARE exact in bf16 is checked while they are staged; a sample with soft targets takes the fp32 forms
-// of binary_pipe_kernel (16x16x4 tiles from the fp32 image, gamma . Y on v_mfma_f32_4x4x1 in the worker) -- same
-// kernel, same hand-offs, a uniform branch per workgroup.
-// Hand-offs: single-writer LDS words only (done[u], tile[m], prog[2], gdone[u], gtile[m], ystage[w]); a wave's LDS
-// operations complete in order, so a counter store after the row stores publishes them (common.hpp: lds_order).
+// Multi-hot targets are exact in bf16, so their emission tiles run on v_mfma_f32_16x16x32_bf16 with the D row split into
+// three bf16 terms on the fly (24 significant bits = 3 x 8: the split is exact, products of two bf16 are exact in fp32,
+// accumulation is fp32).  Whether a sample's targets ARE exact in bf16 is found while they are staged; soft targets that
+// are not take fp32 tiles (16x16x4, from the fp32 image) -- same kernel, same hand-offs, a uniform branch per workgroup.
+// Hand-offs: single-writer LDS words only (done[u], tile[m], prog[2], ystage[w]); a wave's LDS operations complete in
+// order, so a counter store after the row stores publishes them (common.hpp: lds_order).
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
