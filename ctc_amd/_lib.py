@@ -10,6 +10,7 @@ SO_PATH = os.environ.get("CTC_AMD_LIB") or os.path.join(_HERE, "lib", "libctc_am
 
 NOBLANK, BINARY, BLANK = 0, 1, 2
 ABI_VERSION = 2                     # CTC_AMD_ABI_VERSION of include/ctc_amd.h this binding was written for
+ERR_UNSUPPORTED_SHAPE = -2
 ERR_CODE_OVERFLOW = -3
 
 _vp, _i64, _int, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -32,6 +33,8 @@ PROTOTYPES = {
     "ctc_amd_binary_posteriors": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "ctc_amd_lstm_cell_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp,
                                       _vp, _i64, _int, _f32, _vp]),
+    "ctc_amd_lstm_series": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int,
+                                   _vp, _i64, _i64, _int, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctc_amd_dedup_multihot_targets": (_int, [_vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ctc_amd_blank_set_schedule": (_int, [_int]),
     "ctc_amd_workspace_status": (_int, [_vp, _int, _vp, ctypes.POINTER(ctypes.c_uint)]),

@@ -95,9 +95,144 @@ __global__ __launch_bounds__(kLstmThreads) void lstm_cell_step_kernel(LstmParams
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole recurrence of LSTM_cell.forward as ONE launch (the reference's class counts, 33 / 38: I + H <= kSeriesK).
+// One 256-thread workgroup per kSeriesSamples samples walks all T frames: thread r holds gate row r of [W_ih | W_hh] in
+// REGISTERS for the whole launch, [x_t | h_{t-1}] of the samples sits in LDS (16-byte broadcast reads), the cell state
+// stays in LDS between frames, x_{t+1} is in flight while frame t is computed, and h_t goes straight into v_series[t].
+// Same fma chains, in the same order, as lstm_cell_step_kernel: the two paths agree bit for bit.  Two barriers per frame.
+constexpr int kSeriesSamples = 4, kSeriesK = 80;
+
+struct LstmSeriesParams {
+    const float *x, *h0, *c0, *w_ih, *w_hh, *b_ih, *b_hh;
+    int T, B, I, H;
+    float *series;
+    int64_t series_stride_t, series_stride_b;
+    int series_cols;
+    float pad_value;
+    float *gates, *cells;                                    // optional [T][B][4H] activations, [T + 1][B][H] cell states (backward)
+    float *h_out, *c_out;                                    // optional final state [B][H]
+};
+
+__global__ __launch_bounds__(kLstmThreads) void lstm_series_kernel(LstmSeriesParams p)
+{
+    extern __shared__ float4 series_smem[];
+    const int K = p.I + p.H, G = 4 * p.H, K4 = (K + 3) >> 2;
+    float *xh = reinterpret_cast<float *>(series_smem);      // [kSeriesSamples][4 * K4]: [x_t | h_{t-1} | zeros]
+    float *pre = xh + kSeriesSamples * 4 * K4;               // [kSeriesSamples][G]
+    float *cst = pre + kSeriesSamples * G;                   // [kSeriesSamples][H]
+    const int tid = threadIdx.x, b0 = blockIdx.x * kSeriesSamples;
+    const int ns = min(kSeriesSamples, p.B - b0);
+    // gate row `tid` of [W_ih | W_hh] -> registers (zeros behind K: the staged vectors are padded alike)
+    float wr[kSeriesK];
+    float bias = 0.f;
+    if (tid < G) {
+#pragma unroll
+        for (int k = 0; k < kSeriesK; ++k)
+            wr[k] = k < p.I ? p.w_ih[(size_t)tid * p.I + k] : k < K ? p.w_hh[(size_t)tid * p.H + (k - p.I)] : 0.f;
+        bias = p.b_ih[tid] + p.b_hh[tid];
+    }
+    for (int i = tid; i < kSeriesSamples * 4 * K4; i += kLstmThreads) {
+        const int s = i / (4 * K4), k = i - s * 4 * K4;
+        float v = 0.f;
+        if (s < ns && k < p.I) v = p.x[(size_t)(b0 + s) * p.I + k];                       // x_0
+        else if (s < ns && k < K) v = p.h0[(size_t)(b0 + s) * p.H + (k - p.I)];
+        xh[i] = v;
+    }
+    for (int i = tid; i < kSeriesSamples * p.H; i += kLstmThreads) {
+        const int s = i / p.H, j = i - s * p.H;
+        const float c = s < ns ? p.c0[(size_t)(b0 + s) * p.H + j] : 0.f;
+        cst[i] = c;
+        if (p.cells && s < ns) p.cells[(size_t)(b0 + s) * p.H + j] = c;
+    }
+    // this thread's element of the next frame's inputs (kSeriesSamples * I <= 256 is checked on the host)
+    const int xs = tid / p.I, xk = tid - xs * p.I;
+    const bool xmine = xs < ns && tid < kSeriesSamples * p.I;
+    // this thread's (sample, unit) of the cell update (kSeriesSamples * H <= 256)
+    const int cs_ = tid / p.H, cj = tid - cs_ * p.H;
+    const bool cmine = cs_ < ns && tid < kSeriesSamples * p.H;
+    for (int t = 0; t < p.T; ++t) {
+        __syncthreads();                                     // [x_t | h_{t-1}] is complete
+        float xnext = 0.f;
+        if (xmine && t + 1 < p.T) xnext = p.x[((size_t)(t + 1) * p.B + b0 + xs) * p.I + xk];
+        if (tid < G) {
+            float acc[kSeriesSamples];
+#pragma unroll
+            for (int s = 0; s < kSeriesSamples; ++s) acc[s] = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < kSeriesK / 4; ++k4) {
+                if (k4 < K4) {                               // (uniform)
+#pragma unroll
+                    for (int s = 0; s < kSeriesSamples; ++s) {
+                        const float4 v = *reinterpret_cast<const float4 *>(xh + (s * K4 + k4) * 4);
+                        acc[s] = __builtin_fmaf(wr[4 * k4], v.x, acc[s]);
+                        acc[s] = __builtin_fmaf(wr[4 * k4 + 1], v.y, acc[s]);
+                        acc[s] = __builtin_fmaf(wr[4 * k4 + 2], v.z, acc[s]);
+                        acc[s] = __builtin_fmaf(wr[4 * k4 + 3], v.w, acc[s]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < kSeriesSamples; ++s) pre[s * G + tid] = acc[s] + bias;
+        }
+        __syncthreads();                                     // the pre-activations are there; the staged vectors are free
+        if (xmine) xh[xs * 4 * K4 + xk] = xnext;
+        if (cmine) {
+            const int b = b0 + cs_;
+            const float *g4 = pre + cs_ * G;
+            const float gi = sigmoid_f(g4[cj]), gf = sigmoid_f(g4[p.H + cj]), gg = tanhf(g4[2 * p.H + cj]), go = sigmoid_f(g4[3 * p.H + cj]);
+            const float cn = __builtin_fmaf(gf, cst[cs_ * p.H + cj], gi * gg);
+            const float hn = go * tanhf(cn);
+            cst[cs_ * p.H + cj] = cn;
+            xh[cs_ * 4 * K4 + p.I + cj] = hn;                // h_t: the next frame's recurrent input
+            p.series[t * p.series_stride_t + b * p.series_stride_b + cj] = hn;
+            if (p.gates) {
+                float *q = p.gates + ((size_t)t * p.B + b) * G;
+                q[cj] = gi; q[p.H + cj] = gf; q[2 * p.H + cj] = gg; q[3 * p.H + cj] = go;
+            }
+            if (p.cells) p.cells[((size_t)(t + 1) * p.B + b) * p.H + cj] = cn;
+            if (t == p.T - 1) {
+                if (p.h_out) p.h_out[(size_t)b * p.H + cj] = hn;
+                if (p.c_out) p.c_out[(size_t)b * p.H + cj] = cn;
+            }
+        }
+        if (p.series_cols > p.H) {
+            const int np = p.series_cols - p.H;
+            for (int i = tid; i < ns * np; i += kLstmThreads) {
+                const int s = i / np, j = p.H + (i - s * np);
+                p.series[t * p.series_stride_t + (b0 + s) * p.series_stride_b + j] = p.pad_value;
+            }
+        }
+    }
+}
+
 }  // namespace ctc
 
 using namespace ctc;
+
+// The T steps of ctc_amd_lstm_cell_step as one launch, for the reference's class counts (I + H <= 80, H <= 64, I <= 64).
+// Other sizes: CTC_AMD_ERR_UNSUPPORTED_SHAPE (the caller steps frame by frame).
+extern "C" int ctc_amd_lstm_series(const float *x, const float *h0, const float *c0,
+                                   const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                                   int T, int B, int I, int H,
+                                   float *series, int64_t series_stride_t, int64_t series_stride_b, int series_cols, float pad_value,
+                                   float *gates_out, float *cells_out, float *h_out, float *c_out, void *stream)
+{
+    if (!x || !h0 || !c0 || !w_ih || !w_hh || !b_ih || !b_hh || !series) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (T < 1 || B < 1 || I < 1 || H < 1) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (series_cols < H || series_stride_b < series_cols) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (I + H > kSeriesK || 4 * H > kLstmThreads || kSeriesSamples * I > kLstmThreads || kSeriesSamples * H > kLstmThreads)
+        return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    LstmSeriesParams p;
+    p.x = x; p.h0 = h0; p.c0 = c0; p.w_ih = w_ih; p.w_hh = w_hh; p.b_ih = b_ih; p.b_hh = b_hh;
+    p.T = T; p.B = B; p.I = I; p.H = H;
+    p.series = series; p.series_stride_t = series_stride_t; p.series_stride_b = series_stride_b;
+    p.series_cols = series_cols; p.pad_value = pad_value;
+    p.gates = gates_out; p.cells = cells_out; p.h_out = h_out; p.c_out = c_out;
+    const size_t smem = (size_t)kSeriesSamples * (4 * (size_t)((I + H + 3) / 4) + 4 * (size_t)H + H) * sizeof(float);
+    return launch<lstm_series_kernel>(dim3((B + kSeriesSamples - 1) / kSeriesSamples), dim3(kLstmThreads), smem,
+                                      static_cast<hipStream_t>(stream), p);
+}
 
 extern "C" int ctc_amd_lstm_cell_step(const float *x, const float *h, const float *c,
                                       const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,

@@ -59,15 +59,50 @@ def lstm_cell_step(x, h, c, w_ih, w_hh, b_ih, b_hh, series_row=None, pad_value=P
     return h_out, c_out, gates
 
 
+def lstm_series(v_all, h0, c0, w_ih, w_hh, b_ih, b_hh, cols=None, pad_value=PAD_LOGIT, want_backward_state=False):
+    """All T LSTMCell steps in ONE launch (``ctc_amd_lstm_series``; the reference's class counts, I + H <= 80) ->
+    (v_series [T,B,cols], gates [T,B,4H] | None, cells [T+1,B,H] | None), or None when the size is not one the launch
+    takes (step frame by frame with ``lstm_cell_step`` then)."""
+    F._require_hip(v_all, "v_all")
+    T, B, I = v_all.shape
+    H = h0.shape[1]
+    cols = H if cols is None else int(cols)
+    dev = v_all.device
+    args = [t if (t.dtype is torch.float32 and t.is_contiguous()) else t.float().contiguous()
+            for t in (v_all, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    series = torch.empty((T, B, cols), dtype=torch.float32, device=dev)
+    gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev) if want_backward_state else None
+    cells = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev) if want_backward_state else None
+    with F._on_device(dev):
+        rc = _lib.load().ctc_amd_lstm_series(*(t.data_ptr() for t in args), T, B, I, H, series.data_ptr(), series.stride(0),
+                                             series.stride(1), cols, float(pad_value),
+                                             gates.data_ptr() if want_backward_state else None,
+                                             cells.data_ptr() if want_backward_state else None, None, None, F._stream_handle(dev))
+    if rc == _lib.ERR_UNSUPPORTED_SHAPE:
+        return None
+    if rc:
+        _lib.check(rc, "ctc_amd_lstm_series")
+    return series, gates, cells
+
+
 class _SeriesFn(torch.autograd.Function):
-    """v_all [T,B,I], (h0, c0), LSTMCell parameters -> v_series [T,B,cols]: T fused launches; backward = BPTT in torch."""
+    """v_all [T,B,I], (h0, c0), LSTMCell parameters -> v_series [T,B,cols]: one launch for the reference's class counts, T
+    fused launches otherwise; backward = BPTT in torch."""
 
     @staticmethod
     def forward(ctx, v_all, h0, c0, w_ih, w_hh, b_ih, b_hh, cols, pad_value):
         T, B, _ = v_all.shape
         H = h0.shape[1]
-        series = torch.empty((T, B, cols), dtype=torch.float32, device=v_all.device)
         need = any(ctx.needs_input_grad[:7])
+        ctx.H = H
+        whole = lstm_series(v_all, h0, c0, w_ih, w_hh, b_ih, b_hh, cols, pad_value, want_backward_state=need)
+        if whole is not None:
+            series, gates, cells = whole
+            if need:
+                hs = torch.cat([h0.detach().float().unsqueeze(0), series[:, :, :H]])
+                ctx.save_for_backward(v_all, w_ih, w_hh, hs, cells, gates)
+            return series
+        series = torch.empty((T, B, cols), dtype=torch.float32, device=v_all.device)
         hs, cs, gs = [h0], [c0], []
         h, c = h0, c0
         for t in range(T):
@@ -76,7 +111,6 @@ class _SeriesFn(torch.autograd.Function):
                 hs.append(h); cs.append(c); gs.append(g)
         if need:
             ctx.save_for_backward(v_all, w_ih, w_hh, torch.stack(hs), torch.stack(cs), torch.stack(gs))
-        ctx.H = H
         return series
 
     @staticmethod

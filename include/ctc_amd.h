@@ -229,6 +229,18 @@ int ctc_amd_lstm_cell_step(const float *x, const float *h, const float *c,
                            float *series_row, int64_t series_stride_b, int series_cols, float pad_value,
                            void *stream);
 
+/* The whole loop of LSTM_cell.forward (LSTM.py:44-51) over the T frames as ONE launch, for the reference's class counts
+ * (I + H <= 80, I <= 64, H <= 64; other sizes: CTC_AMD_ERR_UNSUPPORTED_SHAPE -- step frame by frame with the call above).
+ *   x [T,B,I]: the cell inputs of all frames (contiguous fp32: `self.v(feat[time])` for every time);  h0, c0 [B,H];
+ *   series: row (t, b) of v_series starts at series + t * series_stride_t + b * series_stride_b (columns as above);
+ *   gates_out [T,B,4H], cells_out [T+1,B,H] (c_0 .. c_T) or NULL: what a backward pass needs;  h_out, c_out [B,H] or NULL:
+ *   the state after the last frame.  Same arithmetic, in the same order, as T calls of ctc_amd_lstm_cell_step. */
+int ctc_amd_lstm_series(const float *x, const float *h0, const float *c0,
+                        const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                        int T, int B, int I, int H,
+                        float *series, int64_t series_stride_t, int64_t series_stride_b, int series_cols, float pad_value,
+                        float *gates_out, float *cells_out, float *h_out, float *c_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,3 +126,45 @@ def test_padded_series_feeds_the_fast_loss_kernel_unchanged(dev):
     assert abs(out["pad"][0] - out["raw"][0]) < 1e-5 * max(1.0, abs(out["raw"][0]))
     assert np.abs(out["pad"][1][:, :, :33] - out["raw"][1]).max() < 1e-6 and np.abs(out["pad"][1][:, :, 33]).max() == 0.0
     assert np.abs(out["pad"][2] - out["raw"][2]).max() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(150, 10, 33, 33), (20, 7, 38, 38), (12, 256, 33, 33), (9, 5, 17, 40), (3, 1, 64, 16)])
+def test_lstm_series_one_launch_is_bit_identical_to_the_steps(dev, shape):
+    """ctc_amd_lstm_series: the T frames in one launch -- same numbers, bit for bit, as T calls of ctc_amd_lstm_cell_step
+    (v_series with and without pad columns, gate activations, cell states), and the numpy restatement within fp32."""
+    import ctc_amd
+    from ctc_amd import producer
+    T, B, I, H = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    rnd = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)          # noqa: E731
+    v_all, h0, c0 = rnd(T, B, I), rnd(B, H), rnd(B, H)
+    w_ih, w_hh, b_ih, b_hh = rnd(4 * H, I) * 0.3, rnd(4 * H, H) * 0.3, rnd(4 * H) * 0.1, rnd(4 * H) * 0.1
+    for cols in (H, H + 1 + (H % 2)):
+        whole = ctc_amd.lstm_series(v_all, h0, c0, w_ih, w_hh, b_ih, b_hh, cols, want_backward_state=True)
+        assert whole is not None, shape
+        series, gates, cells = whole
+        ref = torch.empty_like(series)
+        h, c = h0, c0
+        for t in range(T):
+            h, c, gt = ctc_amd.lstm_cell_step(v_all[t], h, c, w_ih, w_hh, b_ih, b_hh, ref[t], want_gates=True)
+            assert torch.equal(gt, gates[t]) and torch.equal(c, cells[t + 1]), (shape, t)
+        torch.cuda.synchronize()
+        assert torch.equal(series, ref), shape
+        assert torch.equal(cells[0], c0)
+    want = ctc_numpy.lstm_cell_series(np_(v_all), np_(h0), np_(c0), np_(w_ih), np_(w_hh), np_(b_ih), np_(b_hh))[0]
+    assert np.abs(np_(series)[:, :, :H] - want).max() < 2e-5
+
+
+def test_lstm_series_sizes_it_does_not_take_fall_back_to_the_steps(dev):
+    """I + H > 80: the C ABI answers CTC_AMD_ERR_UNSUPPORTED_SHAPE, `lstm_series` returns None, the module steps frame by frame"""
+    import ctc_amd
+    from ctc_amd import producer
+    T, B, H = 6, 4, 158
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)          # noqa: E731
+    v_all, h0, c0 = rnd(T, B, H), rnd(B, H), rnd(B, H)
+    w_ih, w_hh, b_ih, b_hh = rnd(4 * H, H) * 0.1, rnd(4 * H, H) * 0.1, rnd(4 * H) * 0.1, rnd(4 * H) * 0.1
+    assert ctc_amd.lstm_series(v_all, h0, c0, w_ih, w_hh, b_ih, b_hh) is None
+    series = producer._SeriesFn.apply(v_all, h0, c0, w_ih, w_hh, b_ih, b_hh, H, producer.PAD_LOGIT)
+    want = ctc_numpy.lstm_cell_series(np_(v_all), np_(h0), np_(c0), np_(w_ih), np_(w_hh), np_(b_ih), np_(b_hh))[0]
+    assert np.abs(np_(series) - want).max() < 2e-5

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""What the recurrence of LSTM_cell.forward (LSTM.py:44-51) costs on the device at the reference's sizes: torch's own
+nn.LSTMCell loop (the reference), one fused launch per frame (ctc_amd_lstm_cell_step), one launch for all frames
+(ctc_amd_lstm_series).  The per-frame feature head (Linear + BatchNorm + ReLU + Dropout) is torch's in all three and
+is not timed."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import ctc_amd  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+for (T, B, H) in [(150, 10, 33), (150, 64, 33), (150, 256, 33), (150, 10, 38)]:
+    cell = torch.nn.LSTMCell(H, H).to(dev)
+    v_all = torch.randn(T, B, H, device=dev)
+    h0, c0 = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+    p = (cell.weight_ih.detach(), cell.weight_hh.detach(), cell.bias_ih.detach(), cell.bias_hh.detach())
+
+    def torch_loop():
+        with torch.no_grad():
+            h, c = h0, c0
+            out = torch.empty(T, B, H, device=dev)
+            for t in range(T):
+                h, c = cell(v_all[t], (h, c))
+                out[t] = h
+        return out
+
+    def step_loop():
+        out = torch.empty(T, B, H, device=dev)
+        h, c = h0, c0
+        for t in range(T):
+            h, c, _ = ctc_amd.lstm_cell_step(v_all[t], h, c, *p, out[t])
+        return out
+
+    def one_launch():
+        return ctc_amd.lstm_series(v_all, h0, c0, *p)[0]
+
+    err = (one_launch() - torch_loop()).abs().max().item()
+    print("T=%d B=%3d H=%d: torch nn.LSTMCell loop %8.1f us | one fused launch per frame %8.1f us | one launch %7.1f us   (max |diff| to torch %.1e)"
+          % (T, B, H, timed(torch_loop), timed(step_loop), timed(one_launch), err))
