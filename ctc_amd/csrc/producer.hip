@@ -206,6 +206,91 @@ __global__ __launch_bounds__(kLstmThreads) void lstm_series_kernel(LstmSeriesPar
     }
 }
 
+// The backward recurrence of the same loop as one launch.  Only what is SEQUENTIAL stays in the kernel: thread (s, j) owns
+// hidden unit j of sample s for all T frames -- dh and dc live in its registers -- turns (dh_t, dc_t) into the four
+// pre-activation gradients of its unit (written out: [T][B][4H]), and takes dh_{t-1}(s, j) = sum_r W_hh[r][j] dpre(s, r) with
+// column j of W_hh in registers and the pre-activation gradients of the sample's 4H gate rows read from LDS (16-byte
+// broadcasts, double-buffered: one barrier per frame).  Everything that is not a recurrence -- dx_t = dpre_t W_ih, the three
+// parameter gradients -- is a plain GEMM over all frames at once on the result (the caller: rocBLAS through torch).
+constexpr int kSeriesG = 4 * 64;
+
+struct LstmSeriesBwdParams {
+    const float *d_series;                                   // upstream gradient of v_series, unit stride over classes
+    int64_t ds_stride_t, ds_stride_b;
+    const float *gates, *cells, *w_hh;                       // [T][B][4H] (i, f, g, o), [T + 1][B][H], [4H][H]
+    int T, B, H;
+    float *dpre, *dh0, *dc0;                                 // [T][B][4H], [B][H], [B][H]
+};
+
+__global__ __launch_bounds__(kLstmThreads) void lstm_series_bwd_kernel(LstmSeriesBwdParams p)
+{
+    extern __shared__ float4 bwd_smem[];
+    const int G = 4 * p.H, G4 = p.H;                         // (G floats = H float4)
+    float *dp = reinterpret_cast<float *>(bwd_smem);         // [2][kSeriesSamples][G]: the frame's pre-activation gradients
+    const int tid = threadIdx.x, b0 = blockIdx.x * kSeriesSamples;
+    const int ns = min(kSeriesSamples, p.B - b0);
+    const int s = tid / p.H, j = tid - s * p.H;
+    const bool mine = s < ns && tid < kSeriesSamples * p.H;
+    const int b = b0 + (mine ? s : 0);
+    float wc[kSeriesG];                                      // column j of W_hh
+#pragma unroll
+    for (int r = 0; r < kSeriesG; ++r) wc[r] = (mine && r < G) ? p.w_hh[(size_t)r * p.H + j] : 0.f;
+    for (int i = tid; i < 2 * kSeriesSamples * G; i += kLstmThreads) dp[i] = 0.f;
+    float dh = 0.f, dc = 0.f;                                // gradient arriving from frame t + 1
+    // frame T - 1's operands (then always one frame ahead)
+    auto fetch = [&](int t, float (&q)[4], float &ct, float &cp, float &ds) {
+        const float *g = p.gates + ((size_t)t * p.B + b) * G;
+        q[0] = g[j]; q[1] = g[p.H + j]; q[2] = g[2 * p.H + j]; q[3] = g[3 * p.H + j];
+        ct = p.cells[((size_t)(t + 1) * p.B + b) * p.H + j];
+        cp = p.cells[((size_t)t * p.B + b) * p.H + j];
+        ds = p.d_series[t * p.ds_stride_t + b * p.ds_stride_b + j];
+    };
+    float q[4] = {0.f, 0.f, 0.f, 0.f}, ct = 0.f, cp = 0.f, ds = 0.f;
+    if (mine) fetch(p.T - 1, q, ct, cp, ds);
+    for (int t = p.T - 1; t >= 0; --t) {
+        float *cur = dp + (size_t)(t & 1) * kSeriesSamples * G;
+        float qn[4] = {0.f, 0.f, 0.f, 0.f}, ctn = 0.f, cpn = 0.f, dsn = 0.f;
+        if (mine && t > 0) fetch(t - 1, qn, ctn, cpn, dsn);
+        if (mine) {
+            const float gi = q[0], gf = q[1], gg = q[2], go = q[3];
+            const float dht = dh + ds;
+            const float tc = tanhf(ct);
+            const float dct = __builtin_fmaf(dht * go, 1.0f - tc * tc, dc);
+            const float d_i = dct * gg * gi * (1.0f - gi);
+            const float d_f = dct * cp * gf * (1.0f - gf);
+            const float d_g = dct * gi * (1.0f - gg * gg);
+            const float d_o = dht * tc * go * (1.0f - go);
+            cur[s * G + j] = d_i; cur[s * G + p.H + j] = d_f; cur[s * G + 2 * p.H + j] = d_g; cur[s * G + 3 * p.H + j] = d_o;
+            float *o = p.dpre + ((size_t)t * p.B + b) * G;
+            o[j] = d_i; o[p.H + j] = d_f; o[2 * p.H + j] = d_g; o[3 * p.H + j] = d_o;
+            dc = dct * gf;
+        }
+        __syncthreads();                                     // the frame's 4H pre-activation gradients of every sample are in LDS
+        if (mine) {
+            float acc = 0.f;
+            const float4 *row = reinterpret_cast<const float4 *>(cur + s * G);
+#pragma unroll
+            for (int r4 = 0; r4 < kSeriesG / 4; ++r4) {
+                if (r4 < G4) {                               // (uniform)
+                    const float4 v = row[r4];
+                    acc = __builtin_fmaf(wc[4 * r4], v.x, acc);
+                    acc = __builtin_fmaf(wc[4 * r4 + 1], v.y, acc);
+                    acc = __builtin_fmaf(wc[4 * r4 + 2], v.z, acc);
+                    acc = __builtin_fmaf(wc[4 * r4 + 3], v.w, acc);
+                }
+            }
+            dh = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = qn[k];
+        ct = ctn; cp = cpn; ds = dsn;
+    }
+    if (mine) {
+        p.dh0[(size_t)b * p.H + j] = dh;
+        p.dc0[(size_t)b * p.H + j] = dc;
+    }
+}
+
 }  // namespace ctc
 
 using namespace ctc;
@@ -253,4 +338,25 @@ extern "C" int ctc_amd_lstm_cell_step(const float *x, const float *h, const floa
     p.series = series_row; p.series_stride_b = series_stride_b; p.series_cols = series_cols; p.pad_value = pad_value;
     return launch<lstm_cell_step_kernel>(dim3((B + kLstmSamples - 1) / kLstmSamples), dim3(kLstmThreads), smem,
                                          static_cast<hipStream_t>(stream), p);
+}
+
+
+// The backward recurrence of ctc_amd_lstm_series (same sizes): from the upstream gradient of v_series and the state the
+// forward launch saved to the pre-activation gradients of every frame and the gradients of (h0, c0).  The rest of the
+// backward pass is three GEMMs on dpre (ctc_amd/producer.py).
+extern "C" int ctc_amd_lstm_series_backward(const float *d_series, int64_t ds_stride_t, int64_t ds_stride_b,
+                                            const float *gates, const float *cells, const float *w_hh,
+                                            int T, int B, int H, float *dpre_out, float *dh0_out, float *dc0_out, void *stream)
+{
+    if (!d_series || !gates || !cells || !w_hh || !dpre_out || !dh0_out || !dc0_out) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (T < 1 || B < 1 || H < 1) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (4 * H > kSeriesG || kSeriesSamples * H > kLstmThreads) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    LstmSeriesBwdParams p;
+    p.d_series = d_series; p.ds_stride_t = ds_stride_t; p.ds_stride_b = ds_stride_b;
+    p.gates = gates; p.cells = cells; p.w_hh = w_hh;
+    p.T = T; p.B = B; p.H = H;
+    p.dpre = dpre_out; p.dh0 = dh0_out; p.dc0 = dc0_out;
+    const size_t smem = (size_t)2 * kSeriesSamples * 4 * H * sizeof(float);
+    return launch<lstm_series_bwd_kernel>(dim3((B + kSeriesSamples - 1) / kSeriesSamples), dim3(kLstmThreads), smem,
+                                          static_cast<hipStream_t>(stream), p);
 }

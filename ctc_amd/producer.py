@@ -85,6 +85,27 @@ def lstm_series(v_all, h0, c0, w_ih, w_hh, b_ih, b_hh, cols=None, pad_value=PAD_
     return series, gates, cells
 
 
+def lstm_series_backward(d_series, gates, cells, w_hh):
+    """The backward recurrence of ``lstm_series`` in one launch (``ctc_amd_lstm_series_backward``) ->
+    (dpre [T,B,4H], dh0 [B,H], dc0 [B,H]); ``d_series`` [T,B,>=H]: the upstream gradient of v_series."""
+    F._require_hip(d_series, "d_series")
+    T, B, G = gates.shape
+    H = G // 4
+    dev = gates.device
+    ds = d_series if (d_series.dtype is torch.float32 and d_series.stride(2) == 1) else d_series.float().contiguous()
+    w = w_hh if (w_hh.dtype is torch.float32 and w_hh.is_contiguous()) else w_hh.float().contiguous()
+    dpre = torch.empty((T, B, G), dtype=torch.float32, device=dev)
+    dh0 = torch.empty((B, H), dtype=torch.float32, device=dev)
+    dc0 = torch.empty((B, H), dtype=torch.float32, device=dev)
+    with F._on_device(dev):
+        rc = _lib.load().ctc_amd_lstm_series_backward(ds.data_ptr(), ds.stride(0), ds.stride(1), gates.data_ptr(), cells.data_ptr(),
+                                                      w.data_ptr(), T, B, H, dpre.data_ptr(), dh0.data_ptr(), dc0.data_ptr(),
+                                                      F._stream_handle(dev))
+    if rc:
+        _lib.check(rc, "ctc_amd_lstm_series_backward")
+    return dpre, dh0, dc0
+
+
 class _SeriesFn(torch.autograd.Function):
     """v_all [T,B,I], (h0, c0), LSTMCell parameters -> v_series [T,B,cols]: one launch for the reference's class counts, T
     fused launches otherwise; backward = BPTT in torch."""
@@ -98,10 +119,12 @@ class _SeriesFn(torch.autograd.Function):
         whole = lstm_series(v_all, h0, c0, w_ih, w_hh, b_ih, b_hh, cols, pad_value, want_backward_state=need)
         if whole is not None:
             series, gates, cells = whole
+            ctx.one_launch = need
             if need:
                 hs = torch.cat([h0.detach().float().unsqueeze(0), series[:, :, :H]])
                 ctx.save_for_backward(v_all, w_ih, w_hh, hs, cells, gates)
             return series
+        ctx.one_launch = False
         series = torch.empty((T, B, cols), dtype=torch.float32, device=v_all.device)
         hs, cs, gs = [h0], [c0], []
         h, c = h0, c0
@@ -118,6 +141,12 @@ class _SeriesFn(torch.autograd.Function):
     def backward(ctx, d_series):
         v_all, w_ih, w_hh, hs, cs, gs = ctx.saved_tensors
         T, H = v_all.shape[0], ctx.H
+        if ctx.one_launch:                                   # the recurrence in one launch, the rest as GEMMs over all frames
+            dpre, dh0, dc0 = lstm_series_backward(d_series, gs, cs, w_hh)
+            flat = dpre.reshape(-1, 4 * H)
+            db = flat.sum(0)
+            return (dpre @ w_ih.float(), dh0, dc0, flat.t() @ v_all.reshape(-1, v_all.shape[2]).float(),
+                    flat.t() @ hs[:-1].reshape(-1, H), db, db.clone(), None, None)
         dh = torch.zeros_like(hs[0])
         dc = torch.zeros_like(cs[0])
         dv = torch.empty_like(v_all)

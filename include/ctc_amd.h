@@ -241,6 +241,15 @@ int ctc_amd_lstm_series(const float *x, const float *h0, const float *c0,
                         float *series, int64_t series_stride_t, int64_t series_stride_b, int series_cols, float pad_value,
                         float *gates_out, float *cells_out, float *h_out, float *c_out, void *stream);
 
+/* The backward RECURRENCE of ctc_amd_lstm_series as one launch (H <= 64): from the upstream gradient of v_series
+ * (row (t, b) at d_series + t * ds_stride_t + b * ds_stride_b, unit stride over the classes, columns [0,H) read) and the
+ * gates_out / cells_out of the forward launch to dpre_out [T,B,4H] -- the gradient of every frame's gate pre-activations --
+ * and the gradients of the initial state dh0_out, dc0_out [B,H].  What is left of the backward pass has no recurrence in
+ * it: dx = dpre W_ih, dW_ih = sum_tb dpre^T x, dW_hh = sum_tb dpre^T h_{t-1}, db = sum_tb dpre (plain GEMMs). */
+int ctc_amd_lstm_series_backward(const float *d_series, int64_t ds_stride_t, int64_t ds_stride_b,
+                                 const float *gates, const float *cells, const float *w_hh,
+                                 int T, int B, int H, float *dpre_out, float *dh0_out, float *dc0_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

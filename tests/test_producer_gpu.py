@@ -168,3 +168,36 @@ def test_lstm_series_sizes_it_does_not_take_fall_back_to_the_steps(dev):
     series = producer._SeriesFn.apply(v_all, h0, c0, w_ih, w_hh, b_ih, b_hh, H, producer.PAD_LOGIT)
     want = ctc_numpy.lstm_cell_series(np_(v_all), np_(h0), np_(c0), np_(w_ih), np_(w_hh), np_(b_ih), np_(b_hh))[0]
     assert np.abs(np_(series) - want).max() < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(150, 10, 33, 33), (20, 7, 38, 38), (12, 64, 33, 33), (9, 5, 17, 40)])
+def test_lstm_series_backward_one_launch_matches_torch_autograd(dev, shape):
+    """ctc_amd_lstm_series_backward + the three GEMMs against torch.autograd through torch's own nn.LSTMCell loop on the
+    device (same parameters, same inputs, a padded v_series and a random upstream gradient): every gradient."""
+    from ctc_amd import producer
+    T, B, I, H = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    rnd = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)          # noqa: E731
+    cell = torch.nn.LSTMCell(I, H).to(dev)
+    leaves = [rnd(T, B, I), rnd(B, H), rnd(B, H)]
+    up = rnd(T, B, H + 1)
+    out = {}
+    for name in ("torch", "hip"):
+        v_all, h0, c0 = (t.clone().requires_grad_(True) for t in leaves)
+        cell.zero_grad()
+        if name == "torch":
+            h, c, rows = h0, c0, []
+            for t in range(T):
+                h, c = cell(v_all[t], (h, c))
+                rows.append(h)
+            series = torch.stack(rows)
+            (series * up[:, :, :H]).sum().backward()
+        else:
+            series = producer._SeriesFn.apply(v_all, h0, c0, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, H + 1,
+                                              producer.PAD_LOGIT)
+            assert series.grad_fn.one_launch
+            (series * up).sum().backward()
+        out[name] = [np_(t.grad) for t in (v_all, h0, c0, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)]
+    for a, b_, what in zip(out["hip"], out["torch"], ("dv", "dh0", "dc0", "dW_ih", "dW_hh", "db_ih", "db_hh")):
+        scale = max(1.0, float(np.abs(b_).max()))
+        assert np.abs(a - b_).max() <= 3e-5 * scale, (what, shape, np.abs(a - b_).max())

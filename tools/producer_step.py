@@ -51,6 +51,23 @@ for (T, B, H) in [(150, 10, 33), (150, 64, 33), (150, 256, 33), (150, 10, 38)]:
     def one_launch():
         return ctc_amd.lstm_series(v_all, h0, c0, *p)[0]
 
+    from ctc_amd import producer
+    va = v_all.clone().requires_grad_(True)
+
+    def torch_train():
+        cell.zero_grad(); va.grad = None
+        h, c, rows = h0, c0, []
+        for t in range(T):
+            h, c = cell(va[t], (h, c))
+            rows.append(h)
+        torch.stack(rows).sum().backward()
+
+    def hip_train():
+        cell.zero_grad(); va.grad = None
+        producer._SeriesFn.apply(va, h0, c0, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, H, producer.PAD_LOGIT).sum().backward()
+
+    print("    forward + backward: torch nn.LSTMCell loop + autograd %9.1f us | one launch each way + three GEMMs %7.1f us"
+          % (timed(torch_train, 10), timed(hip_train, 10)))
     err = (one_launch() - torch_loop()).abs().max().item()
     print("T=%d B=%3d H=%d: torch nn.LSTMCell loop %8.1f us | one fused launch per frame %8.1f us | one launch %7.1f us   (max |diff| to torch %.1e)"
           % (T, B, H, timed(torch_loop), timed(step_loop), timed(one_launch), err))
