@@ -203,3 +203,25 @@ def test_lstm_series_restatement_matches_the_reference_module(golden):
         assert series.shape == f["v_series"].shape == (10, 10, 33)
         assert np.abs(series - f["v_series"]).max() < tol and np.abs(c - f["c_final"]).max() < tol
         assert np.abs(h - f["v_series"][-1]).max() < tol
+
+
+def test_lstm_series_backward_restatement_matches_torch_autograd():
+    """the BPTT restatement (oracle/ctc_numpy.py) against torch.autograd through torch.nn.LSTMCell on the CPU, float64"""
+    import torch
+    T, B, I, H = 12, 5, 7, 6
+    g = torch.Generator().manual_seed(5)
+    cell = torch.nn.LSTMCell(I, H).double()
+    v = torch.randn(T, B, I, generator=g, dtype=torch.float64, requires_grad=True)
+    h0 = torch.randn(B, H, generator=g, dtype=torch.float64, requires_grad=True)
+    c0 = torch.randn(B, H, generator=g, dtype=torch.float64, requires_grad=True)
+    up = torch.randn(T, B, H, generator=g, dtype=torch.float64)
+    h, c, rows = h0, c0, []
+    for t in range(T):
+        h, c = cell(v[t], (h, c))
+        rows.append(h)
+    (torch.stack(rows) * up).sum().backward()
+    want = [t.grad.numpy() for t in (v, h0, c0, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)]
+    p = [t.detach().numpy() for t in (cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)]
+    got = ctc_numpy.lstm_cell_series_backward(up.numpy(), v.detach().numpy(), h0.detach().numpy(), c0.detach().numpy(), *p)
+    for a, b in zip(got, want):
+        assert np.abs(a - b).max() < 1e-12

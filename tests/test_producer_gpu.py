@@ -198,6 +198,14 @@ def test_lstm_series_backward_one_launch_matches_torch_autograd(dev, shape):
             assert series.grad_fn.one_launch
             (series * up).sum().backward()
         out[name] = [np_(t.grad) for t in (v_all, h0, c0, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)]
-    for a, b_, what in zip(out["hip"], out["torch"], ("dv", "dh0", "dc0", "dW_ih", "dW_hh", "db_ih", "db_hh")):
+    names = ("dv", "dh0", "dc0", "dW_ih", "dW_hh", "db_ih", "db_hh")
+    for a, b_, what in zip(out["hip"], out["torch"], names):
         scale = max(1.0, float(np.abs(b_).max()))
         assert np.abs(a - b_).max() <= 3e-5 * scale, (what, shape, np.abs(a - b_).max())
+    # and against the float64 restatement of the same back-propagation (oracle/ctc_numpy.py)
+    up64 = np_(up)[:, :, :H]
+    want = ctc_numpy.lstm_cell_series_backward(up64, *(np_(t) for t in leaves), np_(cell.weight_ih), np_(cell.weight_hh),
+                                               np_(cell.bias_ih), np_(cell.bias_hh))
+    for a, b_, what in zip(out["hip"], want, names):
+        scale = max(1.0, float(np.abs(b_).max()))
+        assert np.abs(a - b_).max() <= 2e-5 * scale, (what, shape, np.abs(a - b_).max())
