@@ -280,6 +280,9 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
         const int NT = (p.SP + 15) >> 4;
         const int fr = lane & 15, fq = lane >> 4;
         bool bad = !wait_y();
+#ifdef CTC_AMD_FAULT_INJECT                                  // tests/test_status.py: sample 2's first tile wave "starves"
+        if (b == 2 && w == 2) bad = true;
+#endif
         // E = D . Y^T, 16 rows x all labels per job
         int nt = 0;                                          // (diagnostics: which tile of this wave)
         for (int jt = par;; jt += kFlowTileWaves / 2, ++nt) {

@@ -981,3 +981,17 @@ def test_binary_streamed_kernel_target_forms_and_boundaries(dev):
             assert np.isfinite(r["grad"]).all(), (name, T, B, C, S)
             assert (np.abs(r["nll"] - ref["nll"]) <= 3e-6 * np.maximum(1.0, np.abs(ref["nll"]))).all(), (name, T, B, C, S)
             assert np.abs(r["grad"] - ref["grad"]).max() <= 2e-7 * max(1.0, 256.0 / B), (name, T, B, C, S)
+
+
+def test_binary_streamed_kernel_is_deterministic_and_a_shard_is_a_slice(dev):
+    """size-independent properties of the streamed binary kernel at config 3's size: two runs agree bit for bit (single-writer
+    hand-offs, no atomics on the data path), and a shard of the batch scaled by the global batch size is the slice of the
+    full batch's gradient."""
+    import ctc_amd
+    x, y, Tb, L = synth_binary(21, 150, 256, 158, 20, var_T=True)
+    a = run_hip(ctc_amd.binary_ctc_loss, x, y, Tb, L, dev)
+    b = run_hip(ctc_amd.binary_ctc_loss, x, y, Tb, L, dev)
+    assert np.array_equal(a["nll"], b["nll"]) and np.array_equal(a["grad"], b["grad"]) and a["loss"] == b["loss"]
+    lo, hi = 64, 160
+    s = run_hip(ctc_amd.binary_ctc_loss, x[:, lo:hi], y[lo:hi], Tb[lo:hi], L[lo:hi], dev, batch_total=256)
+    assert np.array_equal(s["nll"], a["nll"][lo:hi]) and np.array_equal(s["grad"], a["grad"][:, lo:hi])

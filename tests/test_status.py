@@ -1,7 +1,8 @@
 """A bounded in-launch wait that runs out must be LOUD: NaN in the outputs it could not produce and a bit
 in the workspace status word (include/ctc_amd.h, ctc_amd_workspace_status).  The hand-offs never break in
 the product library, so this builds a fault-injection variant (-DCTC_AMD_FAULT_INJECT: sample 0's alpha
-chain and sample 1's gradient workers pretend their wait ran out) and drives it in a subprocess."""
+chain and sample 1's gradient workers of the no-blank kernel, a tile wave of sample 2 of the streamed binary
+kernel pretend their wait ran out) and drives it in a subprocess."""
 import os
 import subprocess
 import sys
@@ -32,6 +33,18 @@ SCRIPT = textwrap.dedent("""
     except ctc_amd.CtcAmdError as e:
         assert "status 1" in str(e)
     assert ctc_amd.workspace_status() == 0                             # cleared by check_status
+    # the streamed binary kernel: a tile wave of sample 2 reports a wait that ran out -> that sample's loss and every one
+    # of its gradient rows are NaN, the others untouched, status bit 2
+    from tests.helpers import synth_binary
+    x, y, Tb, L = synth_binary(0, 150, 5, 158, 20)
+    xd = x.to(dev).requires_grad_(True)
+    loss, nll = ctc_amd.binary_ctc_loss(xd, y.to(dev), Tb.to(dev), L.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    nll, g = np_(nll), np_(xd.grad)
+    assert np.isnan(nll[2]) and np.isfinite(np.delete(nll, 2)).all(), nll
+    assert np.isnan(g[:, 2]).all() and np.isfinite(np.delete(g, 2, axis=1)).all()
+    assert ctc_amd.workspace_status() == 2
     print("FAULT-INJECTION-OK")
 """)
 
