@@ -41,6 +41,7 @@ PROTOTYPES = {
     "ctc_amd_workspace_status": (_int, [_vp, _int, _vp, ctypes.POINTER(ctypes.c_uint)]),
     "ctc_amd_noblank_best_path": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _int,
                                          _vp, _vp, _vp, _vp]),
+    "ctc_amd_binary_best_path": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "ctc_amd_noblank_posteriors": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _int,
                                           _vp, _vp, _vp, _vp]),
 }

@@ -58,14 +58,6 @@ static size_t binary_smem_bytes(int T, int SP, int S, int CP)
     return ((size_t)(3 * T + 2 * kPrefetch) * SP + 8 + (size_t)S * CP + (size_t)kBinWaves * CP) * 4;
 }
 
-// p = sigmoid(x) in fp32, then the two clamped logs exactly as nn.BCELoss sees them
-__device__ __forceinline__ void bce_logs(float x, float &p, float &lp, float &lq)
-{
-    p = 1.0f / (1.0f + expf(-x));
-    lp = fmaxf(logf(p), -100.0f);
-    lq = fmaxf(logf(1.0f - p), -100.0f);
-}
-
 // The same numbers with fewer instructions (the logs of the MFMA kernel are pure VALU throughput):
 //   * exp(-x): the library expf's own algorithm (product split into a round-to-nearest integer and
 //     a compensated fraction, v_exp_f32, v_ldexp_f32) without its range clamps -- beyond them the

@@ -321,6 +321,14 @@ struct ScalarLengths {
 // Diagnostics only (CTC_AMD_DEBUG_STOP = -(wave+1)): that wave of workgroup 0 stamps
 // (s_memtime, s_memrealtime) pairs into workspace bytes [64,256) at phase boundaries
 // (tools/stamps.py reads them).  Never executes in a normal run (p.stop == 0).
+// (binary variant, NoBlankBinaryCTC.py:146,:112) p = sigmoid(x) in fp32, then the two clamped logs exactly as nn.BCELoss sees them
+__device__ __forceinline__ void bce_logs(float x, float &p, float &lp, float &lq)
+{
+    p = 1.0f / (1.0f + expf(-x));
+    lp = fmaxf(logf(p), -100.0f);
+    lq = fmaxf(logf(1.0f - p), -100.0f);
+}
+
 template <typename P>
 __device__ __forceinline__ void stamp(const P &p, int slot)
 {

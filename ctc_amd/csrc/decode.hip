@@ -29,41 +29,12 @@ struct DecodeParams {
 constexpr int kDecThreads = 256;
 constexpr int kDecWaves = kDecThreads / kWave;
 
+// the max-scan over em[T_b][SP] by ONE wave (one back-pointer byte per cell), the read-out and the walk back
 template <int K>
-__global__ __launch_bounds__(kDecThreads) void noblank_best_path_kernel(DecodeParams p)
+__device__ __forceinline__ void viterbi_wave(const float *em, unsigned char *bp, const DecodeParams &p, int b, int Tb, int L, bool ok)
 {
-    extern __shared__ float4 smem_raw[];
-    float *em = reinterpret_cast<float *>(smem_raw);                       // [T][SP]
-    int *lab = reinterpret_cast<int *>(em + (size_t)p.T * p.SP);            // [SP]
-    unsigned char *bp = reinterpret_cast<unsigned char *>(lab + p.SP);      // [T][SP]: 1 = came from l-1
-    const int b = blockIdx.x, tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
-    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
-    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
-
-    for (int l = tid; l < p.SP; l += kDecThreads) {
-        int k = 0;
-        if (l < L) {
-            k = load_label(p.lab, p.lab64, (int64_t)b * p.S + l) % p.C;
-            if (k < 0) k += p.C;
-        }
-        lab[l] = k;
-    }
-    __syncthreads();
-    for (int t = w; t < Tb; t += kDecWaves) {                               // rows: any C
-        const float *row = p.x + (int64_t)t * p.st + (int64_t)b * p.sb;
-        float m = -__builtin_inff();
-        for (int c = lane; c < p.C; c += kWave) m = fmaxf(m, row[c]);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int c = lane; c < p.C; c += kWave) s += fast_exp(row[c] - m);
-        s = wave_sum(s);
-        const float lsum = fast_log(s);
-        for (int l = lane; l < p.SP; l += kWave) em[t * p.SP + l] = (l < L) ? (row[lab[l]] - m) - lsum : kNeg;
-    }
-    __syncthreads();
-
-    if (w == 0) {
+    const int lane = lane_id();
+    {
         const int l0 = lane * K;
         float a[K];
         float sc = 0.f;
@@ -107,6 +78,84 @@ __global__ __launch_bounds__(kDecThreads) void noblank_best_path_kernel(DecodePa
     }
 }
 
+template <int K>
+__global__ __launch_bounds__(kDecThreads) void noblank_best_path_kernel(DecodeParams p)
+{
+    extern __shared__ float4 smem_raw[];
+    float *em = reinterpret_cast<float *>(smem_raw);                       // [T][SP]
+    int *lab = reinterpret_cast<int *>(em + (size_t)p.T * p.SP);            // [SP]
+    unsigned char *bp = reinterpret_cast<unsigned char *>(lab + p.SP);      // [T][SP]: 1 = came from l-1
+    const int b = blockIdx.x, tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
+    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
+    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
+
+    for (int l = tid; l < p.SP; l += kDecThreads) {
+        int k = 0;
+        if (l < L) {
+            k = load_label(p.lab, p.lab64, (int64_t)b * p.S + l) % p.C;
+            if (k < 0) k += p.C;
+        }
+        lab[l] = k;
+    }
+    __syncthreads();
+    for (int t = w; t < Tb; t += kDecWaves) {                               // rows: any C
+        const float *row = p.x + (int64_t)t * p.st + (int64_t)b * p.sb;
+        float m = -__builtin_inff();
+        for (int c = lane; c < p.C; c += kWave) m = fmaxf(m, row[c]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < p.C; c += kWave) s += fast_exp(row[c] - m);
+        s = wave_sum(s);
+        const float lsum = fast_log(s);
+        for (int l = lane; l < p.SP; l += kWave) em[t * p.SP + l] = (l < L) ? (row[lab[l]] - m) - lsum : kNeg;
+    }
+    __syncthreads();
+
+    if (w == 0) viterbi_wave<K>(em, bp, p, b, Tb, L, ok);
+}
+
+// The same read-out on the lattice of the binary (multi-label sigmoid) variant: cell (t, l) costs
+// -nn.BCELoss()(sigmoid(x[t,b,:]), y[b,l,:]) (NoBlankBinaryCTC.py:112,:88,:146) -- per row the two clamped logs, their
+// difference in a wave-private LDS row, one dot product per label row of the targets.
+template <int K>
+__global__ __launch_bounds__(kDecThreads) void binary_best_path_kernel(DecodeParams p, const float *y)
+{
+    extern __shared__ float4 smem_raw[];
+    float *em = reinterpret_cast<float *>(smem_raw);                       // [T][SP]
+    float *drow = em + (size_t)p.T * p.SP;                                 // [kDecWaves][C]
+    unsigned char *bp = reinterpret_cast<unsigned char *>(drow + (size_t)kDecWaves * p.C);   // [T][SP]
+    const int b = blockIdx.x, w = wave_id(), lane = lane_id();
+    const int64_t Tb64 = p.in_len[b], L64 = p.tgt_len[b];
+    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
+    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
+    const float *yb = y + (int64_t)b * p.S * p.C;
+    float *d = drow + (size_t)w * p.C;
+    const float invC = 1.0f / (float)p.C;
+    for (int t = w; t < Tb; t += kDecWaves) {
+        const float *row = p.x + (int64_t)t * p.st + (int64_t)b * p.sb;
+        float q = 0.f;
+        for (int c = lane; c < p.C; c += kWave) {
+            float pr, lp, lq;
+            bce_logs(row[c], pr, lp, lq);
+            d[c] = lp - lq;
+            q += lq;
+        }
+        q = wave_sum(q);
+        for (int l = 0; l < p.SP; ++l) {                                    // (the wave's own LDS row: in order)
+            float e = kNeg;
+            if (l < L) {
+                float acc = 0.f;
+                for (int c = lane; c < p.C; c += kWave) acc = __builtin_fmaf(yb[(int64_t)l * p.C + c], d[c], acc);
+                e = (wave_sum(acc) + q) * invC;
+            }
+            if (lane == 0) em[t * p.SP + l] = e;
+        }
+    }
+    __syncthreads();
+    if (w == 0) viterbi_wave<K>(em, bp, p, b, Tb, L, ok);
+}
+
 }  // namespace ctc
 
 using namespace ctc;
@@ -139,5 +188,36 @@ extern "C" int ctc_amd_noblank_best_path(const float *x, int64_t stride_t, int64
         case 1: return launch<noblank_best_path_kernel<1>>(grid, block, smem, s, p);
         case 2: return launch<noblank_best_path_kernel<2>>(grid, block, smem, s, p);
         default: return launch<noblank_best_path_kernel<4>>(grid, block, smem, s, p);
+    }
+}
+
+
+// Best alignment on the binary lattice (the reference has no such routine): targets y [B,S,C] float.
+extern "C" int ctc_amd_binary_best_path(const float *x, int64_t stride_t, int64_t stride_b, const float *y,
+                                        const int64_t *in_len, const int64_t *tgt_len,
+                                        int T, int B, int C, int S,
+                                        int32_t *path, float *score, void *workspace, void *stream)
+{
+    (void)workspace;
+    if (!x || !y || !in_len || !tgt_len || !path || !score) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (T < 1 || B < 1 || C < 1 || S < 1) return CTC_AMD_ERR_BAD_ARGUMENT;
+    int K = 1;
+    while (K <= 4 && S > kWave * K) K *= 2;
+    if (K > 4) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    DecodeParams p;
+    p.x = x; p.st = stride_t; p.sb = stride_b;
+    p.lab = nullptr; p.lab64 = 0;
+    p.in_len = in_len; p.tgt_len = tgt_len;
+    p.T = T; p.B = B; p.C = C; p.S = S;
+    p.SP = (S + K - 1) / K * K;
+    p.path = path; p.score = score;
+    const size_t smem = ((size_t)T * p.SP + (size_t)kDecWaves * C) * 4 + (size_t)T * p.SP + 16;
+    if (smem > kMaxLds) return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(B), block(kDecThreads);
+    switch (K) {
+        case 1: return launch<binary_best_path_kernel<1>>(grid, block, smem, s, p, y);
+        case 2: return launch<binary_best_path_kernel<2>>(grid, block, smem, s, p, y);
+        default: return launch<binary_best_path_kernel<4>>(grid, block, smem, s, p, y);
     }
 }

@@ -461,6 +461,34 @@ def noblank_best_path(logits, targets, input_lengths, target_lengths):
     return path, score
 
 
+def binary_best_path(logits, targets, input_lengths, target_lengths):
+    """Best (Viterbi) alignment on the lattice of the binary variant -> (path[B,T] int32, score[B]); ``targets`` [B,S,C]
+    float label rows, ``path[b,t]`` the label ROW occupied at step t (-1 for ``t >= T_b`` or when no alignment exists).
+    Max-semiring twin of NoBlankBinaryCTC's recursion (NoBlankBinaryCTC.py:72-95); SURVEY 8(f) rank 1."""
+    _require_hip(logits, "logits")
+    if logits.dim() != 3 or logits.dtype != torch.float32:
+        raise ValueError("ctc_amd: logits must be float32 [T,B,C]")
+    T, B, C = logits.shape
+    dev = logits.device
+    xs = logits.detach()
+    if xs.stride(2) != 1:
+        xs = xs.contiguous()
+    if _variant_of(targets) != _lib.BINARY or targets.shape[0] != B or targets.shape[2] != C:
+        raise ValueError("ctc_amd: targets must be [B,S,C] float")
+    tg = targets.detach().to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+    S = tg.shape[1]
+    il = _lengths(input_lengths, B, "input_lengths", dev, T)
+    tl = _lengths(target_lengths, B, "target_lengths", dev, S)
+    path = torch.empty((B, T), dtype=torch.int32, device=dev)
+    score = torch.empty(B, dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        rc = _lib.load().ctc_amd_binary_best_path(xs.data_ptr(), xs.stride(0), xs.stride(1), tg.data_ptr(), il.data_ptr(),
+                                                  tl.data_ptr(), T, B, C, S, path.data_ptr(), score.data_ptr(), None,
+                                                  _stream_handle(dev))
+    _lib.check(rc, "ctc_amd_binary_best_path")
+    return path, score
+
+
 def noblank_posteriors(logits, targets, input_lengths, target_lengths):
     """Per-step state posteriors of the no-blank lattice -> (gamma[B,T,S], nll[B]).
 

@@ -177,6 +177,14 @@ int ctc_amd_noblank_best_path(const float *x, int64_t stride_t, int64_t stride_b
                               int32_t *path, float *score,
                               void *workspace, void *stream);
 
+/* The same on the lattice of the binary variant (SURVEY 8f-1 for NoBlankBinaryCTC): y [B,S,C] float label rows;
+ * cell (t, l) costs -nn.BCELoss()(sigmoid(x[t,b,:]), y[b,l,:]) (NoBlankBinaryCTC.py:112,:88,:146).  path [B,T] (label-row
+ * positions, -1 behind T_b or when no alignment exists), score [B] its log-probability. */
+int ctc_amd_binary_best_path(const float *x, int64_t stride_t, int64_t stride_b, const float *y,
+                             const int64_t *in_len, const int64_t *tgt_len,
+                             int T, int B, int C, int S,
+                             int32_t *path, float *score, void *workspace, void *stream);
+
 /* Target construction: the dedup step of the reference's dataset preparation,
  * datasets/charades_ctc_next_pred.py:646-651,663-678 (same code at :503-505,523-531) -- out[b] = the rows of
  * rows[b] whose code is new, in order of first appearance, remaining rows filled with -1 (:676-678);

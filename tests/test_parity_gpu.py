@@ -995,3 +995,29 @@ def test_binary_streamed_kernel_is_deterministic_and_a_shard_is_a_slice(dev):
     lo, hi = 64, 160
     s = run_hip(ctc_amd.binary_ctc_loss, x[:, lo:hi], y[lo:hi], Tb[lo:hi], L[lo:hi], dev, batch_total=256)
     assert np.array_equal(s["nll"], a["nll"][lo:hi]) and np.array_equal(s["grad"], a["grad"][:, lo:hi])
+
+
+@pytest.mark.parametrize("shape", [(20, 4, 10, 5), (150, 16, 158, 20), (40, 3, 300, 12), (90, 2, 40, 70)])
+def test_binary_best_path(dev, shape):
+    """SURVEY 8f-1 on the binary lattice: the Viterbi alignment against the float64 restatement -- optimal score, a
+    monotone path from label row 0 to L_b - 1, the returned path attaining the optimum, soft targets on odd T."""
+    import ctc_amd
+    T, B, C, S = shape
+    x, y, Tb, L = synth_binary(sum(shape) + 2, T, B, C, S, var_T=True, density=0.1)
+    if S % 2:
+        y = y * torch.rand(y.shape, generator=torch.Generator().manual_seed(2))
+    path, score = ctc_amd.binary_best_path(x.to(dev), y.to(dev), Tb.to(dev), L.to(dev))
+    torch.cuda.synchronize()
+    path, score = np_(path), np_(score)
+    rp, rs = ctc_numpy.binary_best_path(np_(x), np_(y), np_(Tb), np_(L))
+    assert np.abs(score - rs).max() <= 2e-5 * np.abs(rs).max()
+    e = ctc_numpy.binary_emissions(np_(x), np_(y))
+    for b in range(B):
+        tb, l = int(Tb[b]), int(L[b])
+        p = path[b]
+        assert (p[tb:] == -1).all() and p[0] == 0 and p[tb - 1] == l - 1
+        d = np.diff(p[:tb])
+        assert ((d == 0) | (d == 1)).all()
+        got = e[np.arange(tb), b, p[:tb]].sum()                 # the returned alignment attains the optimum
+        assert abs(got - rs[b]) <= 1e-4 * max(1.0, abs(rs[b]))
+    assert (path == rp).mean() > 0.97
