@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void blank_tables_kernel(BlankParams p)
 // Only differences alpha+beta-em and the final likelihood (x ln 2) leave the lattice.
 __device__ __forceinline__ float lse2_2(float a, float b)
 {
-    const float m = fmaxf(a, b);
+    const float m = vmax(a, b);
     return m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(a - b)));
 }
 
@@ -379,8 +379,8 @@ __device__ __forceinline__ v2f_t lse2_2x2(v2f_t a, v2f_t b)
     v2f_t l, m;
     l.x = __builtin_amdgcn_logf(t.x);
     l.y = __builtin_amdgcn_logf(t.y);
-    m.x = fmaxf(a.x, b.x);
-    m.y = fmaxf(a.y, b.y);
+    m.x = vmax(a.x, b.x);                                    // (fmaxf would canonicalise both inputs first: eight more VALU operations per step)
+    m.y = vmax(a.y, b.y);
     return m + l;
 }
 

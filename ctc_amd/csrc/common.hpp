@@ -275,6 +275,13 @@ __device__ __forceinline__ float group_reduce(float v, int G)
     return v;
 }
 
+__device__ __forceinline__ float vmax(float a, float b)
+{   // plain v_max_f32: both inputs are VALU results, no NaN canonicalisation wanted (fmaxf costs a v_max x, x, x per input)
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 // natural log for arguments in the normal range (raw v_log_f32, no denormal fix-up)

@@ -18,13 +18,6 @@ namespace ctc {
 
 constexpr int kPrefetch = 4;   // emission rows in flight ahead of the chain
 
-__device__ __forceinline__ float vmax(float a, float b)
-{   // plain v_max_f32: both inputs are VALU results, no NaN canonicalisation wanted
-    float r;
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // em, out: [T][SP] in LDS (SP multiple of K), `dummy`: one spare float for idle lanes.
 // FWD: t = 0..Tb-1 from state 0; !FWD: t = Tb-1..0 from state L-1.
 // ROT: lane 63 is idle (SP <= 63*K), so a wave rotate needs no fill value.
