@@ -126,11 +126,26 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
     const int NGR = (NG + 1) >> 1;                           // gradient groups (two rounds each) in use
     const int MT = (p.T + 15) >> 4;                          // tiles of 16 rows
     const int u = w - kFlowFirstWorker;                      // worker index
-    auto slot_row = [&](int g, int side) {                   // the row of this worker's slot, or -1
-        const int i = kFlowWorkers * g + u;
+    auto slot_row_of = [&](int uu, int g, int side) {        // the row of worker uu's slot (g, side), or -1
+        const int i = kFlowWorkers * g + uu;
         const int t = side ? p.T - 1 - i : i;
         return (side ? t >= H : t < H) ? t : -1;
     };
+    auto slot_row = [&](int g, int side) { return slot_row_of(u, g, side); };
+    // The outermost group (rounds 0 and 1: the rows both scans reach LAST) of four workers of SIMDs 2 and 3 is finished by the two
+    // tile waves of SIMDs 0 and 1, which have been idle since their last tile and whose SIMDs are free once the scans are done:
+    // ten gradient groups per SIMD instead of twelve / eight.  (helper wave 4 <- workers 0, 1; wave 5 <- workers 4, 5)
+#ifdef CTC_X_FLOW_NO_DELEGATE
+    constexpr bool kDelegate = false;
+#else
+    constexpr bool kDelegate = !GAMMA && kFlowTileWaves == 4;
+#endif
+#ifdef CTC_X_FLOW_DELEGATE_OWN                               // (measured: the tile waves of SIMDs 2 and 3 taking a group of their OWN SIMD's
+    constexpr bool kDelegateOwn = true;                      // third worker as well -- no capacity gained, 22.3 against 22.15 us)
+#else
+    constexpr bool kDelegateOwn = false;
+#endif
+    const bool delegated = kDelegate && p.grad && (u == 0 || u == 1 || u == 4 || u == 5 || (kDelegateOwn && (u == 8 || u == 9)));
 
     // rows of this worker, issued before anything else (resident until the gradient: x, then 1 + exp(-x)).
     // Every load is consumed on every path that issued it (binary_pipe_kernel: the vmcnt trap).
@@ -224,6 +239,212 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
     const float gs = p.grad_scale * invC;
     stamp(p, 1);
 
+    // ---------------- the gradient of a group of four rows (the workers; two tile waves for eight delegated groups) ----------------
+    bool starved = false;
+    bool have_lse = false;
+    float c2 = 0.f;                                          // -(log2 of the rows' normaliser)
+    const unsigned voff = 4u * lane;
+    const int lane_l = lane < p.SP ? lane : 0;
+    const bool in_l = lane < L;
+    const float ninf = -__builtin_inff();
+    auto rows_of = [&](int uu, int jg, int (&tt)[4], int (&tl)[4], int &t_hi, int &t_lo) {
+        t_hi = -1; t_lo = p.T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tt[i] = slot_row_of(uu, 2 * jg + (i & 1), i >> 1);
+            tl[i] = tt[i] < Tb ? tt[i] : -1;
+            if (tl[i] >= 0) {
+                t_hi = tl[i] > t_hi ? tl[i] : t_hi;
+                t_lo = tl[i] < t_lo ? tl[i] : t_lo;
+            }
+        }
+    };
+    auto post_ready = [&](int uu, int jg) -> bool {                  // have both scans passed the rows of the group?
+        int tt[4], tl[4], t_hi, t_lo;
+        rows_of(uu, jg, tt, tl, t_hi, t_lo);
+        if (t_hi < 0) return true;
+        const int pa = *(lds_cvint *)sm.prog, pb = *(lds_cvint *)(sm.prog + 1), bad = *(lds_cvint *)sm.fail;
+        if (bad) starved = true;
+        return bad || (pa >= t_hi + 1 && pb >= Tb - t_lo);
+    };
+    auto post = [&](int uu, int jg) {
+        int tt[4], tl[4], t_hi, t_lo;
+        rows_of(uu, jg, tt, tl, t_hi, t_lo);
+        if (t_hi < 0) return;                                // (uniform) no live row
+        lds_order();
+        if (p.SP <= 32) {                                    // (uniform) two rows per register, side by side in the halves of the wave:
+            const int hl = lane & 31;                        // half as many loads, additions, exponentials and reduction steps
+            const bool up = lane >= 32;
+            const bool in_h = hl < L;
+            int tr[2];
+            float z[2], pe[2], sum[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                tr[r] = up ? tl[2 * r + 1] : tl[2 * r];
+                const int off = (tr[r] >= 0 ? tr[r] : 0) * p.SP + (hl < p.SP ? hl : 0);
+                const float za = sm.al[off], zb = sm.be[off], ze = sm.em[off];
+                z[r] = (in_h && tr[r] >= 0) ? za + zb - ze : ninf;
+            }
+            if (!have_lse) {                                 // (uniform) first group of this worker
+                float m[2] = {z[0], z[1]};
+                halves_max2(m[0], m[1], up);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) pe[r] = __builtin_amdgcn_exp2f(z[r] - (tr[r] >= 0 ? m[r] : 0.f));
+#pragma unroll
+                for (int r = 0; r < 2; ++r) sum[r] = pe[r];
+                halves_sum2(sum[0], sum[1], up);
+#pragma unroll
+                for (int k = 3; k >= 0; --k)                 // (every live row's normaliser is the same number: take one)
+                    if (tl[k] >= 0) {                        // (uniform)
+                        const float lse = -m[k >> 1] - __builtin_amdgcn_logf(sum[k >> 1]);
+                        c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lse), (k & 1) ? 32 : 0));
+                    }
+                have_lse = true;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) pe[r] = __builtin_amdgcn_exp2f(z[r] + c2);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) sum[r] = pe[r];
+                halves_sum2(sum[0], sum[1], up);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float inv = __builtin_amdgcn_rcpf(sum[r]);
+                if (hl < p.SP && tr[r] >= 0) sm.be[tr[r] * p.SP + hl] = pe[r] * (gs * inv);
+                if (GAMMA && hl < p.S && tr[r] >= 0)         // posteriors output: gamma_t(l), rows sum to 1
+                    p.gamma[((int64_t)b * p.T + tr[r]) * p.S + hl] = starved ? __builtin_nanf("") : pe[r] * inv;
+            }
+            return;
+        }
+        float z[4], pe[4], sum[4];
+        {   // (idle slots read row 0 and are masked: twelve loads in flight, one wait)
+            float za[4], zb[4], ze[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int off = (tl[k] >= 0 ? tl[k] : 0) * p.SP + lane_l;
+                za[k] = sm.al[off]; zb[k] = sm.be[off]; ze[k] = sm.em[off];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z[k] = (in_l && tl[k] >= 0) ? za[k] + zb[k] - ze[k] : ninf;
+        }
+        if (!have_lse) {                                     // (uniform) first group of this worker
+            float m[4] = {z[0], z[1], z[2], z[3]};
+            wave_max4(m[0], m[1], m[2], m[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pe[k] = __builtin_amdgcn_exp2f(z[k] - (tl[k] >= 0 ? m[k] : 0.f));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum[k] = pe[k];
+            wave_sum4(sum[0], sum[1], sum[2], sum[3]);
+#pragma unroll
+            for (int k = 3; k >= 0; --k)
+                if (tl[k] >= 0) c2 = -m[k] - __builtin_amdgcn_logf(sum[k]);   // (uniform)
+            have_lse = true;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pe[k] = __builtin_amdgcn_exp2f(z[k] + c2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum[k] = pe[k];
+            wave_sum4(sum[0], sum[1], sum[2], sum[3]);
+        }
+        if (lane < p.SP) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tl[k] >= 0) sm.be[tl[k] * p.SP + lane] = pe[k] * (gs * __builtin_amdgcn_rcpf(sum[k]));
+        }
+        if (GAMMA && lane < p.S) {                           // posteriors output: gamma_t(l), rows sum to 1
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tl[k] >= 0)
+                    p.gamma[((int64_t)b * p.T + tl[k]) * p.S + lane] = starved ? __builtin_nanf("") : pe[k] * __builtin_amdgcn_rcpf(sum[k]);
+        }
+    };
+    auto elem = [&](int uu, int jg, unsigned slow4, auto &&P) {   // slow4: the careful-path bits of the group's four slots; P(r, side, j): their sigmoids
+        int tt[4], tl[4], t_hi, t_lo;
+        rows_of(uu, jg, tt, tl, t_hi, t_lo);
+        if (starved) raise_status(p.counter, kStatusBinaryStarved);
+        if constexpr (GAMMA) {                               // posteriors only: rows beyond T_b get zeros, no gradient
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tt[i] >= 0 && tl[i] < 0 && lane < p.S) p.gamma[((int64_t)b * p.T + tt[i]) * p.S + lane] = 0.f;
+            return;
+        }
+        lds_order();
+        f32x4 acc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t_hi >= 0) {
+            {                                                // G = gamma . Y: four labels per batch, two batches per trip
+                const int ti = tl[lane & 3];
+                const float *arow = ti >= 0 ? sm.be + ti * p.SP : sm.zrow;   // (an idle slot contributes a row of zeros)
+                const float *yrow = sm.ys + lane;
+                auto operands = [&](int l0, float4 &fa, float (&fy)[4][CH]) {
+                    fa = *reinterpret_cast<const float4 *>(arow + (l0 < p.SP ? l0 : 0));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) fy[i][j] = yrow[(l0 + i < p.SP ? l0 + i : p.SP - 1) * PD + 64 * j];
+                };
+                auto contract = [&](const float4 &fa, const float (&fy)[4][CH]) {
+                    const float fav[4] = {fa.x, fa.y, fa.z, fa.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(fav[i], fy[i][j], acc[j], 0, 0, 0);
+                };
+                float4 fa0, fa1;
+                float fy0[4][CH], fy1[4][CH];
+                operands(0, fa0, fy0);
+                for (int l0 = 0; l0 < L; l0 += 8) {
+                    operands(l0 + 4, fa1, fy1);
+                    contract(fa0, fy0);
+                    if (l0 + 4 < L) {                        // (uniform)
+                        operands(l0 + 8, fa0, fy0);
+                        contract(fa1, fy1);
+                    }
+                }
+            }
+        }
+        // the usual group -- four live rows, none with tails -- in one piece: one uniform branch instead of a dozen
+        if (!starved && slow4 == 0 && tl[0] >= 0 && tl[1] >= 0 && tl[2] >= 0 && tl[3] >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float *g = p.grad + ((int64_t)tl[i] * p.B + b) * p.C;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float pr = P(i & 1, i >> 1, j);
+                    if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, __builtin_fmaf(pr, gs, -acc[j][i]));
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (tt[i] < 0) continue;                         // wave-uniform
+            float *g = p.grad + ((int64_t)tt[i] * p.B + b) * p.C;
+            const int slot = 2 * (i & 1) + (i >> 1);         // (bit of slow4: slots (2jg, 0), (2jg, 1), (2jg+1, 0), (2jg+1, 1))
+            if (tl[i] < 0 || starved) {                      // (uniform) dead row: zeros; starved: NaN
+                const float fill = starved ? __builtin_nanf("") : 0.f;
+#pragma unroll
+                for (int j = 0; j < CH; ++j)
+                    if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, fill);
+            } else if ((slow4 >> slot) & 1) {                 // (uniform) a row with tails: torch's floored denominator
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float pr = P(i & 1, i >> 1, j);
+                    const float pq = pr * (1.0f - pr);
+                    const float gv = __builtin_fmaf(pr, gs, -acc[j][i]) * (pq * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f)));
+                    if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, gv);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float pr = P(i & 1, i >> 1, j);
+                    if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, __builtin_fmaf(pr, gs, -acc[j][i]));
+                }
+            }
+        }
+    };
+
     // ---------------- the two scans ----------------
     if (w < 2) {
         if (w == 1 && !p.grad && !GAMMA) return;
@@ -276,6 +497,27 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
     if (w < kFlowFirstWorker) {
         __builtin_amdgcn_s_setprio(2);
         const int k = w - 2, back = k & 1, par = k >> 1;
+        const bool helper = kDelegate && p.grad && (k >= 2 || kDelegateOwn);
+        const int c0 = k == 2 ? 0 : k == 3 ? 4 : k == 0 ? 8 : 9;   // its clients: workers c0 (and c0 + 1 for waves 4 and 5)
+        const int ncl = k >= 2 ? 2 : 1;
+        float xh[2][2][2][CH];                               // [client][round 0 / 1][side][chunk]: logits, then sigmoids
+        if (helper) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < ncl)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        const int t = slot_row_of(c0 + c, r, side);
+                        const float *row = p.x + (int64_t)(t >= 0 ? t : 0) * p.st + (int64_t)b * p.sb;
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) {
+                            const int cc = lane + 64 * j;
+                            xh[c][r][side][j] = row[cc < p.C ? cc : p.C - 1];
+                        }
+                    }
+        }
         const int MF = (MT + 1) >> 1;                        // tiles [0, MF) are made front to back, [MF, MT) back to front
         const int NT = (p.SP + 15) >> 4;
         const int fr = lane & 15, fq = lane >> 4;
@@ -409,6 +651,47 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             sm.tile[m] = 1;                                  // (every lane, same value)
             stamp(p, nt == 0 ? 3 : nt == 1 ? 9 : 10);
         }
+        if (helper) {                                        // the delegated groups: sigmoids now, the rest when the scans are done
+            __builtin_amdgcn_s_setprio(0);
+            starved = bad;
+            unsigned slow4[2] = {0u, 0u};
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < ncl)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        float far = 0.f;
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) far = fmaxf(far, fabsf(xh[c][r][side][j] + 5.0f));
+                        const bool careful = __builtin_amdgcn_ballot_w64(!(far < 11.0f)) != 0;   // (the workers' own test)
+                        if (careful) slow4[c] |= 1u << (2 * r + side);
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) {
+                            float sv;
+                            if (careful) {
+                                float lp, lq;
+                                bce_logs_fast_s(xh[c][r][side][j], sv, lp, lq);
+                            } else {
+                                sv = 1.0f + __builtin_amdgcn_exp2f(xh[c][r][side][j] * -kLog2e);
+                            }
+                            xh[c][r][side][j] = __builtin_amdgcn_rcpf(sv);
+                        }
+                    }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c >= ncl) break;
+                int spins = 0;
+                while (!starved && !post_ready(c0 + c, 0)) {
+                    if (++spins >= (1 << 20)) starved = true;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                post(c0 + c, 0);
+                elem(c0 + c, 0, slow4[c], [&](int r, int side, int j) { return xh[c][r][side][j]; });
+            }
+            stamp(p, 11);
+        }
         return;
     }
 
@@ -490,7 +773,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
     // scale written over the rows of `be`; G = gamma . Y on v_mfma_f32_4x4x1 (16 blocks of 4x4, K = 1: the output column
     // is the lane and the four rows are the four accumulator registers -- the layout of the resident rows); then per
     // element a reciprocal, one fma and the store.
-    bool starved = !wait_y();
+    starved = !wait_y();
     // the sigmoids of the resident rows, now, while the scans are on their way to the middle of the sequence
 #pragma unroll
     for (int g = 0; g < kFlowRounds; ++g)
@@ -499,229 +782,12 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             for (int side = 0; side < 2; ++side)
 #pragma unroll
                 for (int j = 0; j < CH; ++j) v[g][side][j] = __builtin_amdgcn_rcpf(v[g][side][j]);
-    bool have_lse = false;
-    float c2 = 0.f;                                          // -(log2 of the rows' normaliser)
-    const unsigned voff = 4u * lane;
-    const int lane_l = lane < p.SP ? lane : 0;
-    const bool in_l = lane < L;
-    const float ninf = -__builtin_inff();
-    constexpr int GA = kFlowRounds - 2;                      // where the rows of the group at hand sit in v[] (they rotate in)
-    auto rows_of = [&](int jg, int (&tt)[4], int (&tl)[4], int &t_hi, int &t_lo) {
-        t_hi = -1; t_lo = p.T;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            tt[i] = slot_row(2 * jg + (i & 1), i >> 1);
-            tl[i] = tt[i] < Tb ? tt[i] : -1;
-            if (tl[i] >= 0) {
-                t_hi = tl[i] > t_hi ? tl[i] : t_hi;
-                t_lo = tl[i] < t_lo ? tl[i] : t_lo;
-            }
-        }
-    };
-    auto post_ready = [&](int jg) -> bool {                  // have both scans passed the rows of the group?
-        int tt[4], tl[4], t_hi, t_lo;
-        rows_of(jg, tt, tl, t_hi, t_lo);
-        if (t_hi < 0) return true;
-        const int pa = *(lds_cvint *)sm.prog, pb = *(lds_cvint *)(sm.prog + 1), bad = *(lds_cvint *)sm.fail;
-        if (bad) starved = true;
-        return bad || (pa >= t_hi + 1 && pb >= Tb - t_lo);
-    };
-    auto post = [&](int jg) {
-        int tt[4], tl[4], t_hi, t_lo;
-        rows_of(jg, tt, tl, t_hi, t_lo);
-        if (t_hi < 0) return;                                // (uniform) no live row
-        lds_order();
-        if (p.SP <= 32) {                                    // (uniform) two rows per register, side by side in the halves of the wave:
-            const int hl = lane & 31;                        // half as many loads, additions, exponentials and reduction steps
-            const bool up = lane >= 32;
-            const bool in_h = hl < L;
-            int tr[2];
-            float z[2], pe[2], sum[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                tr[r] = up ? tl[2 * r + 1] : tl[2 * r];
-                const int off = (tr[r] >= 0 ? tr[r] : 0) * p.SP + (hl < p.SP ? hl : 0);
-                const float za = sm.al[off], zb = sm.be[off], ze = sm.em[off];
-                z[r] = (in_h && tr[r] >= 0) ? za + zb - ze : ninf;
-            }
-            if (!have_lse) {                                 // (uniform) first group of this worker
-                float m[2] = {z[0], z[1]};
-                halves_max2(m[0], m[1], up);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) pe[r] = __builtin_amdgcn_exp2f(z[r] - (tr[r] >= 0 ? m[r] : 0.f));
-#pragma unroll
-                for (int r = 0; r < 2; ++r) sum[r] = pe[r];
-                halves_sum2(sum[0], sum[1], up);
-#pragma unroll
-                for (int k = 3; k >= 0; --k)                 // (every live row's normaliser is the same number: take one)
-                    if (tl[k] >= 0) {                        // (uniform)
-                        const float lse = -m[k >> 1] - __builtin_amdgcn_logf(sum[k >> 1]);
-                        c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lse), (k & 1) ? 32 : 0));
-                    }
-                have_lse = true;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) pe[r] = __builtin_amdgcn_exp2f(z[r] + c2);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) sum[r] = pe[r];
-                halves_sum2(sum[0], sum[1], up);
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float inv = __builtin_amdgcn_rcpf(sum[r]);
-                if (hl < p.SP && tr[r] >= 0) sm.be[tr[r] * p.SP + hl] = pe[r] * (gs * inv);
-                if (GAMMA && hl < p.S && tr[r] >= 0)         // posteriors output: gamma_t(l), rows sum to 1
-                    p.gamma[((int64_t)b * p.T + tr[r]) * p.S + hl] = starved ? __builtin_nanf("") : pe[r] * inv;
-            }
-            return;
-        }
-        float z[4], pe[4], sum[4];
-        {   // (idle slots read row 0 and are masked: twelve loads in flight, one wait)
-            float za[4], zb[4], ze[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int off = (tl[k] >= 0 ? tl[k] : 0) * p.SP + lane_l;
-                za[k] = sm.al[off]; zb[k] = sm.be[off]; ze[k] = sm.em[off];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) z[k] = (in_l && tl[k] >= 0) ? za[k] + zb[k] - ze[k] : ninf;
-        }
-        if (!have_lse) {                                     // (uniform) first group of this worker
-            float m[4] = {z[0], z[1], z[2], z[3]};
-            wave_max4(m[0], m[1], m[2], m[3]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pe[k] = __builtin_amdgcn_exp2f(z[k] - (tl[k] >= 0 ? m[k] : 0.f));
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sum[k] = pe[k];
-            wave_sum4(sum[0], sum[1], sum[2], sum[3]);
-#pragma unroll
-            for (int k = 3; k >= 0; --k)
-                if (tl[k] >= 0) c2 = -m[k] - __builtin_amdgcn_logf(sum[k]);   // (uniform)
-            have_lse = true;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pe[k] = __builtin_amdgcn_exp2f(z[k] + c2);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sum[k] = pe[k];
-            wave_sum4(sum[0], sum[1], sum[2], sum[3]);
-        }
-        if (lane < p.SP) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (tl[k] >= 0) sm.be[tl[k] * p.SP + lane] = pe[k] * (gs * __builtin_amdgcn_rcpf(sum[k]));
-        }
-        if (GAMMA && lane < p.S) {                           // posteriors output: gamma_t(l), rows sum to 1
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (tl[k] >= 0)
-                    p.gamma[((int64_t)b * p.T + tl[k]) * p.S + lane] = starved ? __builtin_nanf("") : pe[k] * __builtin_amdgcn_rcpf(sum[k]);
-        }
-    };
-    auto elem = [&](int jg, int vb) {                        // vb: where the group's rows sit in v[] (a constant after unrolling)
-        int tt[4], tl[4], t_hi, t_lo;
-        rows_of(jg, tt, tl, t_hi, t_lo);
-        if (starved) raise_status(p.counter, kStatusBinaryStarved);
-        if constexpr (GAMMA) {                               // posteriors only: rows beyond T_b get zeros, no gradient
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (tt[i] >= 0 && tl[i] < 0 && lane < p.S) p.gamma[((int64_t)b * p.T + tt[i]) * p.S + lane] = 0.f;
-            return;
-        }
-        lds_order();
-        f32x4 acc[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t_hi >= 0) {
-            {                                                // G = gamma . Y: four labels per batch, two batches per trip
-                const int ti = tl[lane & 3];
-                const float *arow = ti >= 0 ? sm.be + ti * p.SP : sm.zrow;   // (an idle slot contributes a row of zeros)
-                const float *yrow = sm.ys + lane;
-                auto operands = [&](int l0, float4 &fa, float (&fy)[4][CH]) {
-                    fa = *reinterpret_cast<const float4 *>(arow + (l0 < p.SP ? l0 : 0));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < CH; ++j) fy[i][j] = yrow[(l0 + i < p.SP ? l0 + i : p.SP - 1) * PD + 64 * j];
-                };
-                auto contract = [&](const float4 &fa, const float (&fy)[4][CH]) {
-                    const float fav[4] = {fa.x, fa.y, fa.z, fa.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < CH; ++j) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(fav[i], fy[i][j], acc[j], 0, 0, 0);
-                };
-                float4 fa0, fa1;
-                float fy0[4][CH], fy1[4][CH];
-                operands(0, fa0, fy0);
-                for (int l0 = 0; l0 < L; l0 += 8) {
-                    operands(l0 + 4, fa1, fy1);
-                    contract(fa0, fy0);
-                    if (l0 + 4 < L) {                        // (uniform)
-                        operands(l0 + 8, fa0, fy0);
-                        contract(fa1, fy1);
-                    }
-                }
-            }
-        }
-        // the usual group -- four live rows, none with tails -- in one piece: one uniform branch instead of a dozen
-        const unsigned slow4 = (slow >> (4 * jg)) & 15u;     // (bits 4jg .. 4jg+3: slots (2jg, 0), (2jg, 1), (2jg+1, 0), (2jg+1, 1))
-        if (!starved && slow4 == 0 && tl[0] >= 0 && tl[1] >= 0 && tl[2] >= 0 && tl[3] >= 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float *g = p.grad + ((int64_t)tl[i] * p.B + b) * p.C;
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const float pr = v[vb + (i & 1)][i >> 1][j];
-                    if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, __builtin_fmaf(pr, gs, -acc[j][i]));
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (tt[i] < 0) continue;                         // wave-uniform
-            float *g = p.grad + ((int64_t)tt[i] * p.B + b) * p.C;
-            const int slot = 2 * (2 * jg + (i & 1)) + (i >> 1);
-            if (tl[i] < 0 || starved) {                      // (uniform) dead row: zeros; starved: NaN
-                const float fill = starved ? __builtin_nanf("") : 0.f;
-#pragma unroll
-                for (int j = 0; j < CH; ++j)
-                    if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, fill);
-            } else if ((slow >> slot) & 1) {                 // (uniform) a row with tails: torch's floored denominator
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const float pr = v[vb + (i & 1)][i >> 1][j];
-                    const float pq = pr * (1.0f - pr);
-                    const float gv = __builtin_fmaf(pr, gs, -acc[j][i]) * (pq * __builtin_amdgcn_rcpf(fmaxf(pq, 1e-12f)));
-                    if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, gv);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const float pr = v[vb + (i & 1)][i >> 1][j];
-                    if (j < CH - 1 || lane + 64 * j < p.C) bin_store_col<WT>(g, voff, j, __builtin_fmaf(pr, gs, -acc[j][i]));
-                }
-            }
-        }
-    };
-    auto rotate = [&]() {                                    // the next group's rows move into v[GA], v[GA + 1]
-#pragma unroll
-        for (int r = kFlowRounds - 1; r >= 2; --r)
-#pragma unroll
-            for (int side = 0; side < 2; ++side)
-#pragma unroll
-                for (int j = 0; j < CH; ++j) v[r][side][j] = v[r - 2][side][j];
-    };
     stamp(p, 3);
-#ifdef CTC_X_FLOW_ROTATE
-#pragma nounroll
-#else
 #pragma unroll
-#endif
     for (int jg = kFlowGroups - 1; jg >= 0; --jg) {          // rows nearest the middle are ready first
-        if (jg < NGR) {                                      // (uniform)
+        if (jg < NGR && !(jg == 0 && delegated)) {           // (uniform)
             int spins = 0;
-            while (!starved && !post_ready(jg)) {
+            while (!starved && !post_ready(u, jg)) {
                 if (++spins >= (1 << 20)) starved = true;
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -731,15 +797,9 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             else if (jg == 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
 #endif
-            post(jg);
-#ifdef CTC_X_FLOW_ROTATE
-            elem(jg, GA);
+            post(u, jg);
+            elem(u, jg, (slow >> (4 * jg)) & 15u, [&](int r, int side, int j) { return v[2 * jg + r][side][j]; });
         }
-        rotate();
-#else
-            elem(jg, 2 * jg);
-        }
-#endif
     }
     stamp(p, 7);
 }

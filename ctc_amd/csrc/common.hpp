@@ -11,7 +11,7 @@
     (defined(CTC_X_NOSTATUS) || defined(CTC_X_NOREDUCE) || defined(CTC_X_NORETURN) || defined(CTC_X_NOCHAIN) || \
      defined(CTC_X_NOPRIO) || defined(CTC_X_NOREAD) || defined(CTC_X_NOWRITE) || defined(CTC_X_FULL_LATTICE) || \
      defined(CTC_X_GATHER_ONCE) || defined(CTC_X_WMASK) || defined(CTC_X_NOPROG) || defined(CTC_X_NORENORM) || \
-     defined(CTC_X_ROWDPP) || defined(CTC_X_SCALAR_STEP) || defined(CTC_X_NO_POOL_GATHER) || defined(CTC_X_FLOW_NO_GPRIO) || defined(CTC_X_FLOW_ROTATE) || defined(CTC_X_FLOW_NOEXP) || \
+     defined(CTC_X_ROWDPP) || defined(CTC_X_SCALAR_STEP) || defined(CTC_X_NO_POOL_GATHER) || defined(CTC_X_FLOW_NO_GPRIO) || defined(CTC_X_FLOW_NOEXP) || defined(CTC_X_FLOW_NO_DELEGATE) || defined(CTC_X_FLOW_DELEGATE_OWN) || \
      defined(CTC_FLOW_TILE_WAVES))
 #error "CTC_X_* experiment switches need -DCTC_AMD_EXPERIMENTS (A/B builds only, never the product library)"
 #endif
