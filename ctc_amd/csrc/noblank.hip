@@ -564,11 +564,13 @@ extern "C" int ctc_amd_scale_grad(float *grad, const float *grad_out, size_t n, 
 {
     if (!grad || !grad_out) return CTC_AMD_ERR_BAD_ARGUMENT;
     if (n == 0) return 0;
-    // small grid: in the common case (grad_out == 1) every block only reads one float and
-    // leaves, so the launch itself is the cost; 64 blocks still scale 24 MB in ~15 us when they must
+    // in the common case (grad_out == 1) every block only reads one float and leaves: the launch costs one kernel boundary,
+    // 1.7 us in a graph, for any grid up to 2048 blocks (tools/scale_grad_time.py: 64 blocks 1.68, 1024 blocks 1.72 us).
+    // When the gradient must be scaled -- `(loss / accum_steps).backward()`, a loss scaler -- the grid is what moves the
+    // 2 x 24 MB of config 2: 64 blocks 17.7 us, 256 blocks 7.8, 1024 blocks 5.9 (round 3; it was 64).
     size_t blocks = (n / 4 + 255) / 256;
-    // (the launch costs one kernel boundary, ~1.7 us in a graph, whatever the grid: 1 to 256 blocks measured the same)
-    if (blocks > 64) blocks = 64;
+    static const int cap = diag_env("CTC_AMD_SCALE_BLOCKS", 1024);
+    if (blocks > (size_t)cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(scale_grad_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), grad, grad_out, n);
