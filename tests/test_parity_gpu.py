@@ -1021,3 +1021,19 @@ def test_binary_best_path(dev, shape):
         got = e[np.arange(tb), b, p[:tb]].sum()                 # the returned alignment attains the optimum
         assert abs(got - rs[b]) <= 1e-4 * max(1.0, abs(rs[b]))
     assert (path == rp).mean() > 0.97
+
+
+def test_binary_forward_only_launch_gives_the_same_loss(dev):
+    """no gradient requested (validation, `torch.no_grad()`): the streamed kernel leaves after the logs / the tiles / the alpha
+    scan -- same per-sample nll and batch mean, bit for bit, as the launch that also produces the gradient"""
+    import ctc_amd
+    for (T, B, C, S) in [(150, 256, 158, 20), (37, 5, 64, 7), (160, 3, 100, 33)]:
+        x, y, Tb, L = synth_binary(1, T, B, C, S, var_T=True)
+        xd, yd, Tbd, Ld = x.to(dev), y.to(dev), Tb.to(dev), L.to(dev)
+        l0, n0 = ctc_amd.binary_ctc_loss(xd, yd, Tbd, Ld)
+        xg = xd.clone().requires_grad_(True)
+        l1, n1 = ctc_amd.binary_ctc_loss(xg, yd, Tbd, Ld)
+        l1.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(l0, l1.detach()) and torch.equal(n0, n1), (T, B, C, S)
+    assert ctc_amd.workspace_status() == 0
