@@ -282,6 +282,13 @@ __device__ __forceinline__ float vmax(float a, float b)
     return r;
 }
 
+__device__ __forceinline__ float vmax3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 // natural log for arguments in the normal range (raw v_log_f32, no denormal fix-up)

@@ -85,8 +85,8 @@ __device__ __forceinline__ int r16_row(int T, int u, int g, int k)
 struct R16Smem {
     int TP;
     cell_t *em, *al, *be;                                    // (mantissa, exponent) cells, [state][time]
-    float *dummy, *stage;
-    int *cnt, *lab, *occ;
+    float *dummy, *stage, *cs;
+    int *cnt, *lab, *occ, *done;
     __device__ R16Smem(float *base, int T, int SP, int RP)
     {
         TP = r16_pitch(T);
@@ -98,14 +98,16 @@ struct R16Smem {
         cnt = reinterpret_cast<int *>(dummy + 8);
         lab = cnt + 16;
         occ = lab + ((SP + 3) & ~3);                        // [SP] occurrence index, [SPpad] their maximum
-        stage = reinterpret_cast<float *>(occ + ((SP + 3) & ~3) + 4);   // [workers][4 rows][RP]
+        cs = reinterpret_cast<float *>(occ + ((SP + 3) & ~3) + 4);      // [workers][4 rows]: sum over the row slots of the per-row constants
+        done = reinterpret_cast<int *>(cs + 4 * kPipeWorkers);          // workers whose constants are in `cs`
+        stage = cs + 64;                                                 // [workers][4 rows][RP]
     }
 };
 
 static size_t r16_smem_bytes(int T, int SP, int C)
 {
     const int RP = 32 * ((C + 31) / 32);
-    return (size_t)3 * (SP + 1) * r16_pitch(T) * 8 + (8 + 16 + 2 * ((SP + 3) & ~3) + 4) * 4 +
+    return (size_t)3 * (SP + 1) * r16_pitch(T) * 8 + (8 + 16 + 2 * ((SP + 3) & ~3) + 4 + 64) * 4 +
            (size_t)kPipeWorkers * 4 * RP * 4;
 }
 
@@ -364,15 +366,21 @@ struct R16Row {
         for (int k = 0; k < N2; ++k)
             c[k] = *reinterpret_cast<const f2_t *>(row + (k == N2 - 1 ? c_last : off2(k, i16)));
     }
-    // largest element; `maskv` (0 or -inf) is added to the last chunk
-    __device__ __forceinline__ float max(float maskv) const
+    // largest element.  No mask: a lane whose last chunk would stick out of the row was given the row's LAST chunk
+    // instead (`c_last`), and duplicates do not change a maximum.  Plain v_max3 / v_max (the values are loaded
+    // logits: fmaxf would quiet every one of them first, a v_max x, x, x per element).
+    __device__ __forceinline__ float max() const
     {
-        float m = -__builtin_inff();
+        constexpr int n = 4 * N4 + 2 * N2;
+        float e[n];
 #pragma unroll
-        for (int j = 0; j < N4; ++j)
-            m = fmaxf(m, fmaxf(fmaxf(a[j].x, a[j].y), fmaxf(a[j].z, a[j].w)) + ((kLast4 && j == N4 - 1) ? maskv : 0.f));
+        for (int j = 0; j < N4; ++j) { e[4 * j] = a[j].x; e[4 * j + 1] = a[j].y; e[4 * j + 2] = a[j].z; e[4 * j + 3] = a[j].w; }
 #pragma unroll
-        for (int k = 0; k < N2; ++k) m = fmaxf(m, fmaxf(c[k].x, c[k].y) + (k == N2 - 1 ? maskv : 0.f));
+        for (int k = 0; k < N2; ++k) { e[4 * N4 + 2 * k] = c[k].x; e[4 * N4 + 2 * k + 1] = c[k].y; }
+        float m = e[0];
+#pragma unroll
+        for (int i = 1; i + 1 < n; i += 2) m = vmax3(m, e[i], e[i + 1]);
+        if ((n & 1) == 0) m = vmax(m, e[n - 1]);
         return m;
     }
     // the lane's sum of the raw elements (`valid_last`: the last chunk lies inside the row)
@@ -388,27 +396,38 @@ struct R16Row {
         for (int k = 0; k < N2; ++k) s += (k == N2 - 1 && !valid_last) ? 0.f : c[k].x + c[k].y;
         return s;
     }
-    // x <- exp2((x + mask) log2e + mb); returns the lane's sum
-    __device__ __forceinline__ float exp_sum(float maskv, float mb)
+    // x <- exp2(x log2e + mb), the last chunk with `mbl` instead (= mb, or -inf for a lane whose last chunk is a
+    // duplicate: exp2(-inf) = 0); returns the lane's sum.  The multiply-adds and the sums go through the packed
+    // fp32 pipe (two elements per instruction), the exponentials are what they are (quarter rate).
+    __device__ __forceinline__ float exp_sum(float mb, float mbl)
     {
-        float sum = 0.f;
+        const f2_t l2 = {kLog2e, kLog2e};
+        f2_t acc = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < N4; ++j) {
-            const float mk = (kLast4 && j == N4 - 1) ? maskv : 0.f;
-            a[j].x = __builtin_amdgcn_exp2f(__builtin_fmaf(a[j].x + mk, kLog2e, mb));
-            a[j].y = __builtin_amdgcn_exp2f(__builtin_fmaf(a[j].y + mk, kLog2e, mb));
-            a[j].z = __builtin_amdgcn_exp2f(__builtin_fmaf(a[j].z + mk, kLog2e, mb));
-            a[j].w = __builtin_amdgcn_exp2f(__builtin_fmaf(a[j].w + mk, kLog2e, mb));
-            sum += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+            const float b = (kLast4 && j == N4 - 1) ? mbl : mb;
+            const f2_t bb = {b, b};
+            f2_t lo = {a[j].x, a[j].y}, hi = {a[j].z, a[j].w};
+            lo = __builtin_elementwise_fma(lo, l2, bb);
+            hi = __builtin_elementwise_fma(hi, l2, bb);
+            a[j].x = __builtin_amdgcn_exp2f(lo.x);
+            a[j].y = __builtin_amdgcn_exp2f(lo.y);
+            a[j].z = __builtin_amdgcn_exp2f(hi.x);
+            a[j].w = __builtin_amdgcn_exp2f(hi.y);
+            const f2_t e0 = {a[j].x, a[j].y}, e1 = {a[j].z, a[j].w};
+            acc += e0;
+            acc += e1;
         }
 #pragma unroll
         for (int k = 0; k < N2; ++k) {
-            const float mk = k == N2 - 1 ? maskv : 0.f;
-            c[k].x = __builtin_amdgcn_exp2f(__builtin_fmaf(c[k].x + mk, kLog2e, mb));
-            c[k].y = __builtin_amdgcn_exp2f(__builtin_fmaf(c[k].y + mk, kLog2e, mb));
-            sum += c[k].x + c[k].y;
+            const float b = k == N2 - 1 ? mbl : mb;
+            const f2_t bb = {b, b};
+            const f2_t lo = __builtin_elementwise_fma(c[k], l2, bb);
+            c[k].x = __builtin_amdgcn_exp2f(lo.x);
+            c[k].y = __builtin_amdgcn_exp2f(lo.y);
+            acc += c[k];
         }
-        return sum;
+        return acc.x + acc.y;
     }
     // the lane's columns of a staged row in LDS (`trow` = start of the row in the worker's tile)
     __device__ __forceinline__ void to_tile(float *trow, int i16) const
@@ -432,24 +451,22 @@ struct R16Row {
     template <bool NT, bool LS>
     __device__ __forceinline__ void store_grad(float *g, const float *trow, int i16, float rs, bool col_ok, float cb) const
     {
+        const f2_t r2 = {rs, rs}, cb2 = {cb, cb};
 #pragma unroll
         for (int j = 0; j < N4; ++j) {
-            f4_t o = *reinterpret_cast<const f4_t *>(trow + off4(j, i16));
-            if (LS) { o.x -= cb; o.y -= cb; o.z -= cb; o.w -= cb; }
-            f4_t v;
-            v.x = __builtin_fmaf(a[j].x, rs, -o.x);
-            v.y = __builtin_fmaf(a[j].y, rs, -o.y);
-            v.z = __builtin_fmaf(a[j].z, rs, -o.z);
-            v.w = __builtin_fmaf(a[j].w, rs, -o.w);
+            const f4_t o = *reinterpret_cast<const f4_t *>(trow + off4(j, i16));
+            f2_t olo = {o.x, o.y}, ohi = {o.z, o.w};
+            if (LS) { olo -= cb2; ohi -= cb2; }
+            const f2_t xlo = {a[j].x, a[j].y}, xhi = {a[j].z, a[j].w};
+            const f2_t vlo = __builtin_elementwise_fma(xlo, r2, -olo), vhi = __builtin_elementwise_fma(xhi, r2, -ohi);
+            const f4_t v = {vlo.x, vlo.y, vhi.x, vhi.y};
             if (!(kLast4 && j == N4 - 1) || col_ok) grad_store<NT>(reinterpret_cast<f4_t *>(g + off4(j, i16)), v);
         }
 #pragma unroll
         for (int k = 0; k < N2; ++k) {
             f2_t o = *reinterpret_cast<const f2_t *>(trow + off2(k, i16));
-            if (LS) { o.x -= cb; o.y -= cb; }
-            f2_t v;
-            v.x = __builtin_fmaf(c[k].x, rs, -o.x);
-            v.y = __builtin_fmaf(c[k].y, rs, -o.y);
+            if (LS) o -= cb2;
+            const f2_t v = __builtin_elementwise_fma(c[k], r2, -o);
             if (k < N2 - 1 || col_ok) grad_store<NT>(reinterpret_cast<f2_t *>(g + off2(k, i16)), v);
         }
     }
@@ -543,6 +560,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     const cell_t zero = make_cell(0.f, 0);
     for (int i = tid; i < (p.SP + 1) * sm.TP; i += kThreads) sm.em[i - kR16Pad] = zero;   // pads + spare row
     if (tid < 16) sm.cnt[tid] = 0;
+    if (tid == 16) *sm.done = 0;
     if (tid < 8) sm.dummy[tid] = 0.f;
     // LDS-only barrier: __syncthreads() would also wait for every row load of the wave (s_waitcnt
     // vmcnt(0)), but a worker only needs its first group's rows to start
@@ -588,10 +606,27 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             }
             const cell_t a = r16_chain<true>(p, sm, p.T, Tb, L, p.SP);
             stamp(p, 11);
-            // nll = -log alpha[T_b-1, L_b-1] (NoBlankCTC.py:58-68,139)
+            // nll = -log alpha[T_b-1, L_b-1] (NoBlankCTC.py:58-68,139).  The chains ran on emissions that lack a
+            // per-row constant (the row's log-sum-exp and, smoothed, the b sum_n lp[n] term: the posteriors are
+            // normalised per row and do not see it); the workers left the sums of those constants over their live
+            // rows in sm.cs -- 56 values, added here in a fixed order (bitwise reproducible).
+            bool late = false;
+            {
+                int spins = 0;
+                while (*(lds_cvint *)sm.done < kPipeWorkers) {
+                    if (++spins >= kSpinLimit) { late = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                lds_order();
+            }
+            const float csum = wave_sum(lane < 4 * kPipeWorkers ? sm.cs[lane] : 0.f);
             const float am = a.x;
-            float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(cell_k(a) - kXrBias)) * kLn2 : -kNeg;
+            float nll = am > 0.f ? -(__builtin_amdgcn_logf(am) + (float)(cell_k(a) - kXrBias) + csum) * kLn2 : -kNeg;
             if (am != am) nll = am;                          // starved hand-off: NaN, not a plausible number
+            if (late) {
+                raise_status(p.counter, kStatusNoblankStarved);
+                nll = __builtin_nanf("");
+            }
             publish_and_reduce_sum(nll, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
             if (CTC_DIAG(p) == -50 && lane == 0) {                // diagnostic: when the alpha wave (loss ticket) is done
                 const int bid = blockIdx.x, nb = gridDim.x;
@@ -621,54 +656,53 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         gat[s] = trow + (lst[s] < p.SP ? sm.lab[lst[s]] : 0);
     }
     const bool own[2] = {lst[0] < L, lst[1] < L};
-    const float maskv = col_ok ? 0.f : ninf;
     const bool smooth = p.ls_b != 0.f;                       // (wave-uniform)
     cell_t *const spare_w = reinterpret_cast<cell_t *>(sm.dummy);
-    float rs[G];                                             // grad_scale / sum_c exp(x - max), 0 for dead rows
+    // Groups whose four slots all lie beyond the sequence (the last group of the last workers: 14 x 12 slots
+    // for T rows) are skipped -- a group costs its instructions whatever its rows hold.  Wave-uniform.
+    const int Hh = (p.T + 1) >> 1;
+    bool grp[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {                            // P1: extremes first
+    for (int g = 0; g < G; ++g) grp[g] = 2 * kPipeWorkers * g + 2 * u < Hh;
+    float mrow[G];                                           // row maximum
+    // P1a -- what the CHAINS wait for, for all groups first: the labels' logits relative to the row maximum,
+    // e = (x[lab_l] - max) log2e (times a when smoothed), split into 2^floor * 2^frac cells.  The row's
+    // log-sum-exp is a per-row constant that the posteriors never see (they are normalised per row) and the
+    // loss takes as a sum (P1b, below): the 158 exponentials of a row are no longer in front of the chains.
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
         // A SIMD serves its waves oldest first, and the chains cannot start before EVERY worker has
-        // published its first group: without this the youngest worker of a SIMD publishes group 0
-        // after the oldest has finished all three (measured: 3.8 against 2.6 us after entry).
+        // published its first group: the waves that are behind go first.
         if (g == 0) __builtin_amdgcn_s_setprio(2);
-        else if (g == 1) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-        Row &x = v[g];
-        const int t = tv[g];
-        const bool live = t >= 0 && t < Tb;
-        float m = x.max(maskv);
-        row16_allmax(m);
-        float sx = 0.f;                                      // label smoothing: sum of the row's logits
-        if (smooth) {
-            sx = x.sum(col_ok);
-            row16_allsum(sx);
-        }
-        if (CTC_DIAG(p) < 0 && g == 0) stamp(p, 6);               // diagnostic: the first group's rows are there
-        // raw rows -> tile, labels' logits back
-        x.to_tile(trow, i16);
-        lds_order();
-        float xv[2];
+        else __builtin_amdgcn_s_setprio(1);
+        if (grp[g]) {
+            Row &x = v[g];
+            const int t = tv[g];
+            const bool live = t >= 0 && t < Tb;
+            float m = x.max();
+            row16_allmax(m);
+            mrow[g] = m;
+            if (CTC_DIAG(p) < 0 && g == 0) stamp(p, 6);           // diagnostic: the first group's rows are there
+            // raw rows -> tile, labels' logits back
+            x.to_tile(trow, i16);
+            lds_order();
+            float xv[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) xv[s] = *gat[s];
-        lds_order();
-        // the row registers become exp(x - max): P3 needs softmax(x) = that times 1/sum
-        float sum = x.exp_sum(maskv, -m * kLog2e);
-        row16_allsum(sum);
-        const float l2sum = __builtin_amdgcn_logf(sum);
-        rs[g] = live ? p.grad_scale * __builtin_amdgcn_rcpf(sum) : 0.f;
-        // emissions e = log_softmax(x)[lab_l] in log2 units, split into 2^floor * 2^frac
-        // (smoothed: a lp[c_l] + b sum_n lp[n], sum_n lp[n] = (sum_n x_n - C max) log2e - C log2 sum, NoBlankCTC.py:100-107)
-        const float s2 = smooth ? p.ls_b * __builtin_fmaf(sx - (float)p.C * m, kLog2e, -(float)p.C * l2sum) : 0.f;
+            for (int s = 0; s < 2; ++s) xv[s] = *gat[s];
+            lds_order();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float ec = __builtin_fmaf(xv[s] - m, kLog2e, -l2sum);
-            const float e2 = fmaxf(smooth ? __builtin_fmaf(p.ls_a, ec, s2) : ec, kXrMinLog2);
-            const float fl = __builtin_floorf(e2);
-            const float pm = __builtin_amdgcn_exp2f(e2 - fl);
-            cell_t *dst = (live && lst[s] < p.SP) ? sm.em + lst[s] * sm.TP + t : spare_w;
-            *dst = own[s] ? make_cell(pm, (int)fl) : zero;
+            for (int s = 0; s < 2; ++s) {
+                const float ec = (xv[s] - m) * kLog2e;
+                const float e2 = fmaxf(smooth ? p.ls_a * ec : ec, kXrMinLog2);
+                const float fl = __builtin_floorf(e2);
+                const float pm = __builtin_amdgcn_exp2f(e2 - fl);
+                cell_t *dst = (live && lst[s] < p.SP) ? sm.em + lst[s] * sm.TP + t : spare_w;
+                *dst = own[s] ? make_cell(pm, (int)fl) : zero;
+            }
+            lds_order();
+        } else {
+            mrow[g] = 0.f;
         }
-        lds_order();
         sm.cnt[u] = 4 * (g + 1);                             // publishes the four slots (same wave: in order)
         // nothing of the next group may be scheduled in front of this publication: the chains wait
         // for it, and the next group's first instruction waits for loads that are still in flight
@@ -676,6 +710,36 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         if (CTC_DIAG(p) < 0) stamp(p, 8 + g);                     // diagnostic: group g published
     }
     __builtin_amdgcn_s_setprio(0);
+    // P1b -- beside the running chains: the row registers become exp(x - max) (P3 needs softmax(x) = that times
+    // 1/sum), the per-row constant of the loss is  -a log2 sum + b sum_n lp[n]  in log2 units
+    // (sum_n lp[n] = (sum_n x_n - C max) log2e - C log2 sum, NoBlankCTC.py:100-107; plain loss: a = 1, b = 0).
+    float rs[G];                                             // grad_scale / sum_c exp(x - max), 0 for dead rows
+    float cacc = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        rs[g] = 0.f;
+        if (!grp[g]) continue;
+        Row &x = v[g];
+        const int t = tv[g];
+        const bool live = t >= 0 && t < Tb;
+        const float m = mrow[g];
+        float sx = 0.f;                                      // label smoothing: sum of the row's logits
+        if (smooth) {
+            sx = x.sum(col_ok);
+            row16_allsum(sx);
+        }
+        const float mb = -m * kLog2e;
+        float sum = x.exp_sum(mb, col_ok ? mb : ninf);
+        row16_allsum(sum);
+        const float l2sum = __builtin_amdgcn_logf(sum);
+        rs[g] = live ? p.grad_scale * __builtin_amdgcn_rcpf(sum) : 0.f;
+        const float cst = smooth ? __builtin_fmaf(p.ls_b, __builtin_fmaf(sx - (float)p.C * m, kLog2e, -(float)p.C * l2sum), -p.ls_a * l2sum)
+                                 : -l2sum;
+        cacc += live ? cst : 0.f;
+    }
+    if (i16 == 0) sm.cs[4 * u + rho] = cacc;
+    lds_order();
+    if (lane == 0) __hip_atomic_fetch_add(sm.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     stamp(p, 2);
     // More samples than CUs: the workgroup that follows this one on the CU (dispatch order: block + one full
     // round of CUs, the same XCD under round-robin placement -- speed only) will want the rows of ITS sample.
@@ -700,8 +764,14 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     const cell_t *const zero_r = sm.em + (size_t)p.SP * sm.TP;   // the spare state row of em stays zero
 
     // P3: middle-out, one look at the chains' progress per group
+    // Every live row has the SAME total sum_l alpha_t(l) beta_t(l) (the sample's likelihood), so the exponent
+    // that brings a row's terms into range need not be the row's own maximum: a lane keeps the one of the first
+    // live row it meets (`kref`) and the later groups skip that reduction.
+    int kref = 0;
+    bool have_ref = false;
 #pragma unroll
     for (int g = G - 1; g >= 0; --g) {
+        if (!grp[g]) continue;
         int need_a = 0, need_b = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -734,7 +804,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         const int t = tv[g];
         const bool live = t >= 0 && t < Tlive;
         // gamma_t(l) = alpha_t(l) beta_t(l) / sum_l' (...): mantissa products, exponents added and
-        // shifted by the row's largest
+        // shifted by the reference exponent
         // (beta comes with the emission of its own row: q = beta p, see r16_chain)
         float pr[2];
         int ks[2];
@@ -747,11 +817,14 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             pr[s] = in ? a.x * bb.x * __builtin_amdgcn_rcpf(e.x) : 0.f;
             ks[s] = cell_k(a) + cell_k(bb) - cell_k(e);
         }
-        int km = max(pr[0] > 0.f ? ks[0] : 0, pr[1] > 0.f ? ks[1] : 0);
-        row16_allmax(km);
+        if (__builtin_amdgcn_ballot_w64(live && !have_ref) != 0) {   // (wave-uniform branch)
+            int km = max(pr[0] > 0.f ? ks[0] : 0, pr[1] > 0.f ? ks[1] : 0);
+            row16_allmax(km);
+            if (live && !have_ref) { kref = km; have_ref = true; }
+        }
         float z[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) z[s] = __builtin_amdgcn_ldexpf(pr[s], ks[s] - km);
+        for (int s = 0; s < 2; ++s) z[s] = __builtin_amdgcn_ldexpf(pr[s], ks[s] - kref);
         float tot = z[0] + z[1];
         row16_allsum(tot);
         // (smoothed: grad = (1 - b) softmax - a occupancy - b, all times 1/B on live rows)
