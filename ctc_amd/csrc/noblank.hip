@@ -43,6 +43,7 @@ struct NoblankParams {
     unsigned *counter;
     int next_round;             // > 0: B exceeds one round of workgroups -- blocks prefetch for block + next_round
     float ls_a, ls_b;           // label-smoothed emission a lp[c_l] + b sum_n lp[n] (NoBlankCTC.py:100-107); 1, 0: plain
+    int koff;                   // noblank_km_kernel: what the exponent recurrence starts with (log2 of the path count / 2)
 };
 
 #ifndef CTC_NOBLANK_THREADS
@@ -378,6 +379,9 @@ __global__ __launch_bounds__(kThreads) void noblank_fused_kernel(NoblankParams p
 #include "noblank_pipe.hpp"
 #include "noblank_xr.hpp"
 #include "noblank_r16.hpp"
+#ifdef CTC_AMD_DIAGNOSTICS                                    // measured and not taken: A/B through CTC_AMD_KM=1
+#include "noblank_km.hpp"
+#endif
 
 namespace ctc {
 
@@ -446,7 +450,7 @@ static int noblank_run(const float *x, int64_t stride_t, int64_t stride_b,
     static const bool debug_nograd = diag_env("CTC_AMD_DEBUG_NOGRAD") != 0;       // diagnostic: forward only
     if (debug_nograd) p.grad = nullptr;
     p.counter = static_cast<unsigned *>(workspace);
-    p.lattice = nullptr; p.slab = 0; p.next_round = 0;
+    p.lattice = nullptr; p.slab = 0; p.next_round = 0; p.koff = 0;
     const bool smooth = label_smoothing >= 0.f;
     p.ls_b = smooth ? (1.f - label_smoothing) / (float)C : 0.f;
     p.ls_a = smooth ? label_smoothing - p.ls_b : 1.f;
@@ -482,6 +486,28 @@ static int noblank_run(const float *x, int64_t stride_t, int64_t stride_b,
         if (!no_r16 && aligned && r16_shape(C, n4, n2) && p.SP <= 31 && rsmem <= kMaxLds) {
             // logits + gradient beyond the memory-side cache (256 MB): non-temporal gradient stores
             const bool nt = (size_t)8 * T * B * C > ((size_t)230 << 20);
+#ifdef CTC_AMD_DIAGNOSTICS
+            // the chains split over exponent and mantissa waves (noblank_km.hpp) wherever its arrays fit and the
+            // number of lattice paths leaves two mantissas room in fp32
+            static const bool use_km = diag_env("CTC_AMD_KM") != 0;
+            const size_t ksmem = km_smem_bytes(T, p.SP, C);
+            const int koff = km_offset(T, S);
+            if (use_km && ksmem <= kMaxLds && koff >= 0) {
+                p.koff = koff;
+                p.next_round = (B > cus && (size_t)T * ((C * 4 + 127) / 128) <= (size_t)kKmWorkers * kWave) ? cus : 0;
+#define CTC_KM_CASE(K, A, Bq)                                                                           \
+                case K: return nt ? launch<noblank_km_kernel<A, Bq, true>>(grid, block, ksmem, s, p)      \
+                                  : launch<noblank_km_kernel<A, Bq, false>>(grid, block, ksmem, s, p);
+                switch (4 * n4 + n2) {
+                    CTC_KM_CASE(1, 0, 1) CTC_KM_CASE(2, 0, 2) CTC_KM_CASE(4, 1, 0) CTC_KM_CASE(5, 1, 1)
+                    CTC_KM_CASE(6, 1, 2) CTC_KM_CASE(8, 2, 0) CTC_KM_CASE(9, 2, 1) CTC_KM_CASE(10, 2, 2)
+                    CTC_KM_CASE(12, 3, 0) CTC_KM_CASE(13, 3, 1) CTC_KM_CASE(14, 3, 2)
+                    default: return nt ? launch<noblank_km_kernel<4, 0, true>>(grid, block, ksmem, s, p)
+                                       : launch<noblank_km_kernel<4, 0, false>>(grid, block, ksmem, s, p);
+                }
+#undef CTC_KM_CASE
+            }
+#endif
             p.next_round = (B > cus && (size_t)T * ((C * 4 + 127) / 128) <= (size_t)kPipeWorkers * kWave) ? cus : 0;
 #define CTC_R16_CASE(K, A, Bq)                                                                          \
             case K: return nt ? launch<noblank_r16_kernel<A, Bq, true>>(grid, block, rsmem, s, p)         \
@@ -601,7 +627,7 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
     // the batch-mean slot of the in-launch reduction lands in a spare workspace word
     p.counter = static_cast<unsigned *>(workspace);
     p.loss = reinterpret_cast<float *>(static_cast<char *>(workspace) + 32);
-    p.lattice = nullptr; p.slab = 0; p.next_round = 0; p.ls_a = 1.f; p.ls_b = 0.f;
+    p.lattice = nullptr; p.slab = 0; p.next_round = 0; p.ls_a = 1.f; p.ls_b = 0.f; p.koff = 0;
     size_t smem = noblank_smem_bytes(T, p.SP, C);
     if (smem > kMaxLds) {
         smem = noblank_tables_bytes(p.SP, C);
