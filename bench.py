@@ -16,11 +16,13 @@ N>1 (launched by torch.distributed.run, one rank per GPU, RCCL):
   --scaling strong BASELINE configs[3]: ONE global batch (--global-batch, default 2048), seeded
                    once and sliced -- rank r owns shard_bounds(B, r, N); N=1 runs all of it.
 Either way the gradient scale is 1/B_global, there is no gradient communication, and the
-loss contributions are summed by RCCL: by default the step losses of one hipGraph replay
-(`--graph-steps`, 50) travel in ONE all-reduce of a 50-vector, issued asynchronously behind the
-replay; `--loss-bucket 1` is one all-reduce per step captured into the graph, reported as the
-secondary figure `per_step_collective` of the default run (on this stack a collective kernel
-node beside the step's kernels costs the graph ~18 us per step).
+loss contributions are summed by RCCL with ONE all-reduce of the 4-byte scalar per step (the
+BASELINE north_star; `--loss-bucket 1`, the default), captured into the hipGraph with the step
+and enqueued on the launch stream itself behind `scale_grad` (`--collective-stream same`: no
+cross-stream edge in the graph, no collective kernel resident beside the next loss launch;
+`side` = asynchronous on RCCL's own stream).  `--loss-bucket M` sends the losses of M steps
+through one all-reduce instead; the default run reports that form (M = one graph replay) as the
+secondary figure `bucketed`.  A capture that fails falls back to eager issue and says so.
 
 Prints ONE JSON line on rank 0.
 """
@@ -68,12 +70,15 @@ def parse():
                     help="graph: steps are replayed from a captured hipGraph; eager: one ctypes call per launch")
     ap.add_argument("--graph-steps", type=int, default=50, help="steps captured per hipGraph")
     ap.add_argument("--loss-bucket", type=int, default=None,
-                    help="N>1: steps per RCCL all-reduce of the loss scalars (default 1 = one all-reduce per step)")
+                    help="N>1: steps per RCCL all-reduce of the loss scalars (default 1 = one all-reduce per step, the north_star form)")
     ap.add_argument("--no-eager-python", action="store_true", help="skip the secondary CTCLoss.apply + backward() timing")
     ap.add_argument("--collective-launch", default="graph", choices=["graph", "eager"],
                     help="N>1, one all-reduce per step: graph = the asynchronous all-reduce of every step is captured into "
                          "the hipGraph with the step (RCCL supports capture); eager = steps and collectives issued one by one "
                          "from Python (host-bound: ~22 us per torch.distributed call)")
+    ap.add_argument("--collective-stream", default="same", choices=["same", "side"],
+                    help="all-reduces captured into the hipGraph: same = a blocking all-reduce on the launch stream behind "
+                         "scale_grad (serial, no cross-stream dependency); side = asynchronous, forked onto a side stream")
     ap.add_argument("--watchdog-seconds", type=int, default=900,
                     help="end the process (exit code 3) if the run has not finished by then: a collective inside a "
                          "hipGraph that never completes is invisible to torch.distributed's own watchdog")
@@ -85,7 +90,8 @@ def parse():
                          "workgroup.  Off by default: inside a captured graph the cross-stream dependencies cost more than the gate saves")
     ap.add_argument("--occupant", type=int, default=None,
                     help="--rehearse-collective: a stand-in for the collective's kernel (a 1-rank all-reduce launches none) -- "
-                         "K workgroups with rcclGenericKernel's footprint resident for --occupant-us (default 2 / 15 us)")
+                         "K workgroups with rcclGenericKernel's footprint resident for --occupant-us on a side stream, and the "
+                         "co-residence measurements of DESIGN.md section 5 (`coresident` in the output)")
     ap.add_argument("--occupant-us", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 collective backend: nccl = RCCL over xGMI; gloo only to rehearse the multi-rank "
@@ -299,12 +305,12 @@ def main():
         wl = Workload(variant, Bl, Bg, dev, seed=rank)
     B = wl.B
 
-    # N > 1 default: the step losses of one graph replay share ONE all-reduce (an M-vector; `--loss-bucket 1` = one per step,
-    # reported as the secondary figure `per_step_collective`).  Measured on one GPU with stand-in collective kernels
-    # (`--rehearse-collective`): a kernel node on a second stream costs a captured graph ~18 us per
-    # step in cross-stream dependencies, issued from Python it is host-bound at ~40 us, and a collective kernel that is
-    # resident when a B = #CUs loss launch starts takes whole CUs away from it (15 -> 23 us).
-    bucket = a.loss_bucket if a.loss_bucket is not None else (None if not a.rehearse_collective else 1) if coll else None
+    # N > 1: ONE all-reduce of the scalar loss per step is the primary figure (BASELINE north_star / configs[3]);
+    # `--loss-bucket M` amortises it over M steps and is what the default run reports as `bucketed`.  (Measured on one GPU
+    # with stand-in collective kernels, DESIGN.md section 5: a collective kernel node on a SECOND stream costs a captured
+    # graph ~18 us per step in cross-stream dependencies and, resident beside a B = #CUs loss launch, takes whole CUs away
+    # from it -- hence the same-stream placement below.)
+    bucket = (a.loss_bucket if a.loss_bucket is not None else 1) if coll else None
     per_step_collective = coll and bucket == 1
     # one all-reduce per step INSIDE the hipGraph (asynchronous: it runs on RCCL's stream beside the next step's kernel)
     in_graph = per_step_collective and a.launch == "graph" and a.collective_launch == "graph" and a.backend == "nccl"
@@ -323,21 +329,38 @@ def main():
     side = torch.cuda.Stream(dev)                            # the collectives are ordered behind this stream
     occ_sink = torch.zeros(4, dtype=torch.int32, device=dev)
 
-    def capture(m, collective=False, gate=False, occupant=0):
-        """m steps per graph.  collective: one asynchronous all-reduce per step, issued from a side stream that forks off
-        behind the step's kernels -- optionally behind the collective gate (so that RCCL's kernel is dispatched after the
-        NEXT step's loss launch has filled the chip) and, when rehearsing on one GPU, behind `occupant` stand-in workgroups
-        with the collective kernel's footprint."""
+    def drain():
+        """no NCCL work outstanding and nothing in flight on the device: a capture must not begin while the process
+        group's watchdog thread still polls the events of earlier asynchronous all-reduces (a hipEventQuery from
+        another thread invalidates a capture in the global error mode -- round 3's `scale_grad launch failed: 901`)"""
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+        torch.cuda.synchronize()
+
+    def capture(m, collective=False, gate=False, occupant=0, placement=None):
+        """m steps per graph.  collective: one all-reduce of the step's loss per step -- placement "same": a blocking
+        all-reduce enqueued on the capture stream itself behind scale_grad; "side": asynchronous, issued from a side
+        stream that forks off behind the step's kernels, optionally behind the collective gate (so that RCCL's kernel is
+        dispatched after the NEXT step's loss launch has filled the chip) and, when rehearsing on one GPU, behind
+        `occupant` stand-in workgroups with the collective kernel's footprint."""
+        placement = placement or a.collective_stream
+        if occupant or gate:
+            placement = "side"                              # (the stand-in kernel and the gate belong to the side stream)
+        drain()
         gs = []
         for r in rings:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 main = torch.cuda.current_stream(dev)
                 s = main.cuda_stream
                 works = []
                 for j in range(m):
                     wl.step(r.data_ptr() + 4 * j, ws, s)
-                    if collective:
+                    if collective and placement == "same":
+                        dist.all_reduce(r[j:j + 1], op=dist.ReduceOp.SUM)
+                    elif collective:
                         side.wait_stream(main)
                         with torch.cuda.stream(side):
                             if gate and j < m - 1:          # (only when a loss launch follows in this graph: the gate is bounded, not free)
@@ -348,36 +371,58 @@ def main():
                             works.append(dist.all_reduce(r[j:j + 1], op=dist.ReduceOp.SUM, async_op=True))
                 for w in works:                             # (joins RCCL's stream back into the capture)
                     w.wait()
-                if collective:
+                if collective and placement == "side":
                     main.wait_stream(side)
             gs.append(g)
+        torch.cuda.synchronize()
         return gs
 
+    def try_capture(what, *args, **kw):
+        """a capture that fails (any exception) is reported in one line and returns None: the caller falls back"""
+        try:
+            return capture(*args, **kw)
+        except Exception as e:                              # noqa: BLE001
+            print("bench: capture of %s failed (%s: %s)" % (what, type(e).__name__, str(e).splitlines()[0][:200]),
+                  file=sys.stderr, flush=True)
+            try:
+                torch.cuda.synchronize()
+            except Exception:                               # noqa: BLE001
+                pass
+            return None
+
+    pending = [None, None]
     if coll:                                                # communicator set up outside any capture
         dist.all_reduce(rings[0][:1], op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         rings[0].zero_()
     graphs = []
     occ_lib = None
-    n_occ = a.occupant if a.occupant is not None else (2 if (a.rehearse_collective and world == 1) else 0)
+    n_occ = a.occupant or 0                                 # (only on request: the default rehearsal runs exactly what N > 1 runs)
     if n_occ:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import coresident
         occ_lib = coresident.load_occupant()
     use_gate = bool(a.collective_gate) and variant != "blank"
+    capture_note = None
     if in_graph:
-        try:
-            graphs = capture(M, collective=True, gate=use_gate, occupant=n_occ)
-            graphs[0].replay()
-            torch.cuda.synchronize()
-        except Exception as e:                              # noqa: BLE001 -- any failure: the eager path still works
-            print("bench: collective capture failed (%s: %s); issuing steps and all-reduces eagerly"
-                  % (type(e).__name__, str(e)[:200]), file=sys.stderr)
+        graphs = try_capture("the step with its all-reduce", M, collective=True, gate=use_gate, occupant=n_occ)
+        if graphs is not None:
+            try:
+                graphs[0].replay()
+                torch.cuda.synchronize()
+            except Exception as e:                          # noqa: BLE001
+                print("bench: replay of the captured collective failed (%s)" % str(e).splitlines()[0][:200], file=sys.stderr)
+                graphs = None
+        if graphs is None:                                  # the eager path still works: steps and all-reduces one by one
+            capture_note = "collective capture failed: steps and all-reduces issued eagerly (host-bound)"
             in_graph, launch, M, graphs = False, "eager", 1, []
             bucket = 1
     elif launch == "graph":
-        graphs = capture(M)
-    pending = [None, None]
+        graphs = try_capture("the step", M)
+        if graphs is None:
+            capture_note = "graph capture failed: steps issued eagerly"
+            launch, M, graphs = "eager", 1, []
+            bucket = bucket or 1
     state = {"i": 0}
 
     def run_steps(n, launch=launch, graphs=graphs, M=M, bucket=bucket, graph_collective=in_graph):
@@ -439,26 +484,29 @@ def main():
     # (`per_step_collective`, when the primary run is the bucketed default)
     per_step = None
     if coll and not per_step_collective and a.launch == "graph" and a.backend == "nccl" and launch == "graph":
-        try:
-            gp = capture(M, collective=True, gate=use_gate, occupant=0)
+        gp = try_capture("the per-step all-reduce (secondary figure)", M, collective=True, gate=use_gate, occupant=0)
+        if gp is None:
+            per_step = {"error": "capture failed"}
+        else:
             run_steps(M, launch="graph", graphs=gp, M=M, bucket=1, graph_collective=True)
             npst = max(M, min(K, 200) // M * M)
             elp = timed(npst, launch="graph", graphs=gp, M=M, bucket=1, graph_collective=True)
             per_step = {"value": round(B_total(world, wl, a) * npst / elp, 1), "unit": "samples/s", "steps": npst,
                         "ms_per_step": round(elp / npst * 1e3, 6), "launch": "graph", "graph_steps": M,
-                        "loss_allreduce_bucket": 1, "collective_launch": "in the hipGraph, one asynchronous all-reduce per step"}
-        except Exception as e:                              # noqa: BLE001
-            per_step = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                        "loss_allreduce_bucket": 1, "collective_launch": "in the hipGraph, one all-reduce per step (%s stream)" % a.collective_stream}
     bucketed = None
     if per_step_collective and a.launch == "graph":
         Mb = max(1, min(a.graph_steps, K))
-        gb = capture(Mb)
-        run_steps(Mb, launch="graph", graphs=gb, M=Mb, bucket=Mb, graph_collective=False)
-        nb = max(Mb, K // Mb * Mb)
-        elb = timed(nb, launch="graph", graphs=gb, M=Mb, bucket=Mb, graph_collective=False)
-        bucketed = {"value": round(B_total(world, wl, a) * nb / elb, 1), "unit": "samples/s", "steps": nb,
-                    "ms_per_step": round(elb / nb * 1e3, 6), "launch": "graph", "graph_steps": Mb,
-                    "loss_allreduce_bucket": Mb}
+        gb = try_capture("the bucketed form (secondary figure)", Mb)
+        if gb is None:
+            bucketed = {"error": "capture failed"}
+        else:
+            run_steps(Mb, launch="graph", graphs=gb, M=Mb, bucket=Mb, graph_collective=False)
+            nb = max(Mb, K // Mb * Mb)
+            elb = timed(nb, launch="graph", graphs=gb, M=Mb, bucket=Mb, graph_collective=False)
+            bucketed = {"value": round(B_total(world, wl, a) * nb / elb, 1), "unit": "samples/s", "steps": nb,
+                        "ms_per_step": round(elb / nb * 1e3, 6), "launch": "graph", "graph_steps": Mb,
+                        "loss_allreduce_bucket": Mb, "what": "the same steps, the losses of one graph replay in ONE all-reduce"}
 
     # rehearsal on one GPU: the same graph with the stand-in collective kernel, gated and not, and without a collective
     coresident = None
@@ -467,9 +515,13 @@ def main():
                                   "per lane), resident %.0f us, where each step's all-reduce kernel would run" % (n_occ, a.occupant_us)}
         for label, kw in (("gated_us_per_step", dict(collective=True, gate=True, occupant=n_occ)),
                           ("ungated_us_per_step", dict(collective=True, gate=False, occupant=n_occ)),
-                          ("allreduce_only_us_per_step", dict(collective=True, gate=False, occupant=0)),
+                          ("allreduce_only_us_per_step", dict(collective=True, gate=False, occupant=0, placement="side")),
+                          ("allreduce_same_stream_us_per_step", dict(collective=True, gate=False, occupant=0, placement="same")),
                           ("no_collective_us_per_step", dict(collective=False))):
-            gx = capture(M, **kw)
+            gx = try_capture(label, M, **kw)
+            if gx is None:
+                coresident[label] = None
+                continue
             nb = max(M, K // M * M)
             run_steps(M, launch="graph", graphs=gx, M=M, bucket=M, graph_collective=True)
             elx = sorted(timed(nb, launch="graph", graphs=gx, M=M, bucket=M, graph_collective=True) for _ in range(3))[1]
@@ -518,7 +570,7 @@ def main():
             "config": {"workload": wl.name, "variant": variant, "per_gpu_batch": B, "global_batch": Bg,
                        "T": wl.T, "C": wl.C, "S": wl.S, "parallelism": "dp%d (batch-sharded)" % world,
                        "collective": (a.backend if coll else None),
-                       "collective_launch": (("in the hipGraph, one asynchronous all-reduce per step" if in_graph else
+                       "collective_launch": (("in the hipGraph, one all-reduce per step on the %s stream" % ("launch" if (a.collective_stream == "same" and not n_occ and not use_gate) else "side") if in_graph else
                                               "eager, one asynchronous all-reduce per step" if per_step_collective else
                                               "one all-reduce per %d steps" % bucket) if coll else None),
                        "launch": launch, "graph_steps": M if launch == "graph" else None,
@@ -546,6 +598,9 @@ def main():
             out["coresident"] = coresident
         if coll:
             out["config"]["collective_gate"] = bool(use_gate and in_graph)
+            out["config"]["workload"] += "; loss all-reduce every %s" % ("step" if bucket == 1 else "%d steps" % bucket)
+        if capture_note:
+            out["config"]["note"] = capture_note
         # (before anything multi-threaded runs on the host: the checker's OpenMP workers keep spinning for a while after
         # their last parallel region and the autograd engine's thread wake-ups then take 2-3x as long)
         eager = eager_python_step(wl, 300 if variant != "blank" else 20) if (world == 1 and not a.no_eager_python) else None
@@ -587,4 +642,12 @@ def B_total(world, wl, a):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:                              # noqa: BLE001 -- a failed run says why in one line and exits non-zero
+        import traceback
+        traceback.print_exc()
+        print("bench: FAILED (%s: %s)" % (type(e).__name__, str(e).splitlines()[0][:300] if str(e) else ""), file=sys.stderr, flush=True)
+        os._exit(1)

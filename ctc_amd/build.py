@@ -100,17 +100,34 @@ HOST_EXT_DIR = os.path.join(LIBDIR, "ext")
 HOST_EXT_SO = os.path.join(HOST_EXT_DIR, "ctc_amd_autograd_ext.so")
 
 
+HOST_EXT_STAMP = os.path.join(HOST_EXT_DIR, "built_for_torch.txt")
+
+
+def host_ext_is_current():
+    """the extension exists, is newer than its source and was built against the torch that is imported now"""
+    import torch
+    src = os.path.join(CSRC, "autograd_ext.cpp")
+    if not (os.path.exists(HOST_EXT_SO) and os.path.exists(HOST_EXT_STAMP)):
+        return False
+    if os.path.getmtime(HOST_EXT_SO) < os.path.getmtime(src):
+        return False
+    return open(HOST_EXT_STAMP).read().strip() == torch.__version__
+
+
 def build_host_ext(verbose=False):
     """csrc/autograd_ext.cpp -> lib/ext/ctc_amd_autograd_ext.so: the C++ autograd node around the C-ABI calls (host code
     only, g++ through torch.utils.cpp_extension, in-tree so that it travels with the snapshot).  Optional: without it
     the Python Functions of ctc_amd/functional.py issue the same launches."""
+    import torch
     src = os.path.join(CSRC, "autograd_ext.cpp")
-    if os.path.exists(HOST_EXT_SO) and os.path.getmtime(HOST_EXT_SO) >= os.path.getmtime(src):
+    if host_ext_is_current():
         return HOST_EXT_SO
     from torch.utils import cpp_extension
     os.makedirs(HOST_EXT_DIR, exist_ok=True)
     cpp_extension.load(name="ctc_amd_autograd_ext", sources=[src], build_directory=HOST_EXT_DIR, extra_cflags=["-O2"],
                        with_cuda=False, verbose=verbose, is_python_module=False)
+    with open(HOST_EXT_STAMP, "w") as f:
+        f.write(torch.__version__)
     return HOST_EXT_SO
 
 

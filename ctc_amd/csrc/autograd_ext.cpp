@@ -72,7 +72,12 @@ struct CtcFn : public torch::autograd::Function<CtcFn> {
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list gout)
     {
-        const int64_t stream = ctx->saved_data["stream"].toInt();
+        // once differentiable, like the Python Function it stands in for (torch.autograd.function.once_differentiable):
+        // the gradient below comes out of a raw kernel and carries no graph -- under create_graph=True it would silently be
+        // treated as a constant
+        // (the engine runs backward with grad mode ON exactly when create_graph=True)
+        TORCH_CHECK(!at::GradMode::is_enabled(),
+                    "ctc_amd: the CTC loss is differentiable once (create_graph=True / double backward is not supported)");
         at::Tensor grad;
         auto it = ctx->saved_data.find("grad");
         if (it != ctx->saved_data.end() && it->second.isTensor()) {
@@ -81,6 +86,7 @@ struct CtcFn : public torch::autograd::Function<CtcFn> {
         } else {
             auto saved = ctx->get_saved_variables();
             at::Tensor x = saved[0].detach();
+            const int64_t stream = ctx->saved_data["stream"].toInt();   // (the recomputation uses the forward's stream and workspace)
             const int64_t B = x.size(1), bt = ctx->saved_data["batch_total"].toInt();
             at::Tensor nll = at::empty({B}, x.options()), loss = at::empty({}, x.options());
             grad = at::empty({x.size(0), B, x.size(2)}, x.options());
@@ -91,7 +97,15 @@ struct CtcFn : public torch::autograd::Function<CtcFn> {
         at::Tensor g = gout[0];
         if (g.scalar_type() != at::kFloat || g.device() != grad.device() || !g.is_contiguous())
             g = g.to(grad.device(), at::kFloat).contiguous();
-        const int rc = g_abi.scale(grad.data_ptr<float>(), g.data_ptr<float>(), (size_t)grad.numel(), reinterpret_cast<void *>(stream));
+        // on the stream that is current NOW (the engine has made it wait for the forward's), as the Python Function does
+        int64_t cur = 0;
+        {
+            pybind11::gil_scoped_acquire gil;
+            // (leaked on purpose: a static pybind11 object would be destroyed after the interpreter is gone)
+            static pybind11::object *raw = new pybind11::object(pybind11::module_::import("torch._C").attr("_cuda_getCurrentRawStream"));
+            cur = (*raw)(grad.device().index()).cast<int64_t>();
+        }
+        const int rc = g_abi.scale(grad.data_ptr<float>(), g.data_ptr<float>(), (size_t)grad.numel(), reinterpret_cast<void *>(cur));
         TORCH_CHECK(rc == 0, "ctc_amd: scale_grad launch failed (", rc, ")");
         return {grad, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }

@@ -104,7 +104,9 @@ __device__ __forceinline__ void note_arrival(unsigned *counter, int b)
 }
 __device__ __forceinline__ void reset_arrivals(unsigned *counter)
 {
-    if (!gate_on(counter)) return;
+    // unconditional: a gate that switches the counting on WHILE a launch is in flight lets some of its workgroups count
+    // and the finisher (which may have read "off") must still leave the words at 0 for the next gate -- sixteen relaxed
+    // stores by one lane of the launch's last workgroup
     for (int sh = 0; sh < 16; ++sh) __hip_atomic_store(arrival_shard(counter, sh), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -38,12 +38,14 @@ def _stream_handle(device):
 
 
 def _workspace(variant, T, B, C, S, device, stream=None):
-    """Zero-initialised once, one per (device, stream): see include/ctc_amd.h.
+    """Zero-initialised once, one per (device, stream, variant): see include/ctc_amd.h.
 
-    A workspace that has become too small is SUPERSEDED, never freed: a hipGraph captured earlier
-    still holds its raw pointer (the calls are capture-safe, tests capture after an eager warm-up),
-    and replaying it must not write counters and lattices into memory the allocator has handed to
-    someone else.  The list only grows when a larger shape arrives (a handful of times per process)."""
+    A workspace that has become too small is SUPERSEDED, not freed: a hipGraph captured earlier still holds its raw
+    pointer (the calls are capture-safe, tests capture after an eager warm-up), and replaying it must not write
+    counters and lattices into memory the allocator has handed to someone else.  So that a loop whose shapes keep
+    growing (length-bucketed batches with rising T) does not pile up one buffer per new maximum, a superseding
+    buffer is at least 1.5x its predecessor: O(log) buffers, at most ~3x the largest need held in total.
+    `release_workspaces()` frees them all when the caller knows no captured graph is alive."""
     shape = (variant, T, B, C, S)
     need = _ws_need.get(shape)
     if need is None:
@@ -53,8 +55,25 @@ def _workspace(variant, T, B, C, S, device, stream=None):
     if held is None:
         held = _workspaces[key] = []
     if not held or held[-1].numel() < need:
-        held.append(torch.zeros(need, dtype=torch.uint8, device=device))
+        size = need if not held else max(need, held[-1].numel() + held[-1].numel() // 2)
+        held.append(torch.zeros((size + 4095) & ~4095, dtype=torch.uint8, device=device))
     return held[-1]
+
+
+def release_workspaces(device=None):
+    """Frees the hidden workspaces of `device` (all devices if None), superseded ones included, and returns the bytes
+    released.  ONLY when no hipGraph that captured a call of this module is still going to be replayed (it holds the raw
+    pointers) -- eager loops may call it at any time: it synchronises the device(s) first, and the next call allocates
+    afresh.  Also drops the entries of streams that no longer exist (the key carries the raw stream handle)."""
+    want = None if device is None else torch.device(device).index
+    freed = 0
+    for key in list(_workspaces):
+        if want is not None and key[0] != want:
+            continue
+        torch.cuda.synchronize(key[0])
+        freed += sum(w.numel() for w in _workspaces[key])
+        del _workspaces[key]
+    return freed
 
 
 STATUS_BITS = {1: "no-blank launch", 2: "binary launch", 4: "blank-CTC launch"}
@@ -309,12 +328,21 @@ def _load_host_ext():
     from .build import HOST_EXT_SO
     if not os.path.exists(HOST_EXT_SO):
         return None
-    spec = importlib.util.spec_from_file_location("ctc_amd_autograd_ext", HOST_EXT_SO)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    lib = _lib.load()
-    addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value
-    mod.set_abi(addr(lib.ctc_amd_noblank_loss_grad), addr(lib.ctc_amd_binary_loss_grad), addr(lib.ctc_amd_scale_grad))
+    try:                                                       # optional: anything wrong with it (built against another torch:
+        from .build import host_ext_is_current                 # undefined symbols, a missing entry point) -> the Python Functions
+        if not host_ext_is_current():
+            raise ImportError("built for another torch version")
+        spec = importlib.util.spec_from_file_location("ctc_amd_autograd_ext", HOST_EXT_SO)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        lib = _lib.load()
+        addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value
+        mod.set_abi(addr(lib.ctc_amd_noblank_loss_grad), addr(lib.ctc_amd_binary_loss_grad), addr(lib.ctc_amd_scale_grad))
+    except (ImportError, OSError, AttributeError, RuntimeError) as e:
+        import warnings
+        warnings.warn("ctc_amd: the C++ autograd node (%s) is unusable (%s: %s); the Python Function issues the same "
+                      "launches" % (os.path.basename(HOST_EXT_SO), type(e).__name__, e))
+        return None
     _host_ext = mod
     return mod
 

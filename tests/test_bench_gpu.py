@@ -36,22 +36,35 @@ def test_bench_line_n1():
 
 
 def test_bench_collective_path_rehearsal():
+    """`--rehearse-collective` runs exactly what an N > 1 run does by default: one all-reduce of the scalar per step
+    (the north_star form), captured into the hipGraph on the launch stream, the bucketed form as the secondary figure."""
     d = _bench("--rehearse-collective")
     c = d["config"]
     assert c["collective"] == "nccl" and c["loss_allreduce_bucket"] == 1 and c["launch"] == "graph"
-    assert c["collective_launch"].startswith("in the hipGraph")
+    assert c["collective_launch"].startswith("in the hipGraph") and "launch stream" in c["collective_launch"]
+    assert "loss all-reduce every step" in c["workload"] and "note" not in c, c
     assert math.isfinite(d["value"]) and d["value"] > 1e6
-    # A one-rank all-reduce launches no kernel; the rehearsal also puts workgroups with RCCL's kernel footprint where each
-    # step's all-reduce kernel would run (a kernel node on a second stream is what costs a captured
-    # graph its time, which is why real N > 1 runs default to one all-reduce per graph replay).
-    co = d["coresident"]
-    for k in ("gated_us_per_step", "ungated_us_per_step", "allreduce_only_us_per_step", "no_collective_us_per_step"):
-        assert math.isfinite(co[k]) and co[k] > 5.0, co
-    assert abs(co["allreduce_only_us_per_step"] - co["no_collective_us_per_step"]) < 2.0, co
-    assert co["ungated_us_per_step"] > co["no_collective_us_per_step"] + 3.0, co
+    assert d["bucketed"]["loss_allreduce_bucket"] == 20 and math.isfinite(d["bucketed"]["value"])
+    b = _bench("--rehearse-collective", "--loss-bucket", "20")
+    assert b["config"]["loss_allreduce_bucket"] == 20 and "every 20 steps" in b["config"]["workload"]
+    assert math.isfinite(b["per_step_collective"]["value"])
     e = _bench("--rehearse-collective", "--collective-launch", "eager")
     assert e["config"]["launch"] == "eager" and e["config"]["collective_launch"].startswith("eager")
     assert math.isfinite(e["value"]) and e["value"] > 1e5
+
+
+def test_bench_collective_coresidence_measurements():
+    """A one-rank all-reduce launches no kernel; `--occupant K` puts workgroups with RCCL's kernel footprint where each
+    step's all-reduce kernel would run on a side stream (a kernel node on a second stream is what
+    costs a captured graph its time) and also times the same-stream placement the default uses."""
+    d = _bench("--rehearse-collective", "--occupant", "2")
+    co = d["coresident"]
+    for k in ("gated_us_per_step", "ungated_us_per_step", "allreduce_only_us_per_step", "allreduce_same_stream_us_per_step",
+              "no_collective_us_per_step"):
+        assert co[k] is not None and math.isfinite(co[k]) and co[k] > 5.0, co
+    assert abs(co["allreduce_only_us_per_step"] - co["no_collective_us_per_step"]) < 2.0, co
+    assert abs(co["allreduce_same_stream_us_per_step"] - co["no_collective_us_per_step"]) < 2.0, co
+    assert co["ungated_us_per_step"] > co["no_collective_us_per_step"] + 3.0, co
 
 
 def test_collective_gate_returns_and_arrival_words_reset():

@@ -160,3 +160,53 @@ def test_cpp_node_is_graph_capturable_and_shares_the_python_workspace(dev):
     torch.cuda.synchronize()
     assert torch.equal(xd.grad, eager_grad)
     assert ctc_amd.workspace_status() == 0
+
+
+def test_host_extension_that_does_not_load_falls_back_quietly(monkeypatch, tmp_path):
+    """The node is optional: an .so that cannot be imported (built against another torch, truncated) must make the first
+    CTCLoss.apply fall back to the Python Function with ONE warning, not raise (round-3 advice)."""
+    import warnings
+    import ctc_amd.functional as F
+    from ctc_amd import build
+    bad = tmp_path / "ctc_amd_autograd_ext.so"
+    bad.write_bytes(b"not an ELF file")
+    monkeypatch.setattr(build, "HOST_EXT_SO", str(bad))
+    monkeypatch.setattr(build, "host_ext_is_current", lambda: True)
+    monkeypatch.setattr(F, "_host_ext", False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert F._load_host_ext() is None
+    assert len(w) == 1 and "Python Function" in str(w[0].message)
+    assert F._host_ext is None
+    # and a stamp for another torch version is "not current"
+    monkeypatch.undo()
+    monkeypatch.setattr(build, "HOST_EXT_STAMP", str(tmp_path / "stamp.txt"))
+    (tmp_path / "stamp.txt").write_text("0.0.0")
+    assert build.host_ext_is_current() is False
+
+
+@pytest.mark.gpu
+def test_cpp_node_is_once_differentiable_and_scales_on_the_current_stream(dev):
+    """create_graph=True must raise like the Python Function's once_differentiable (the raw-kernel gradient carries no
+    graph), and backward issued under another current stream scales the gradient on THAT stream (round-3 advice)."""
+    import ctc_amd
+    x, lab, Tb, L = synth_noblank(3, 40, 6, 20, 5)
+    xd = x.to(dev).requires_grad_(True)
+    args = (lab.to(dev), Tb.to(dev), L.to(dev))
+    loss = ctc_amd.CTCLoss.apply(xd, *args)
+    with pytest.raises(RuntimeError, match="differentiable once"):
+        torch.autograd.grad(loss, xd, create_graph=True)
+    # reference gradient (default stream), then the same with backward under a side stream and an upstream factor
+    xd.grad = None
+    ctc_amd.CTCLoss.apply(xd, *args).backward()
+    torch.cuda.synchronize()
+    ref = xd.grad.clone()
+    xd.grad = None
+    loss = ctc_amd.CTCLoss.apply(xd, *args)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        (3.0 * loss).backward()
+    side.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(xd.grad, 3.0 * ref)

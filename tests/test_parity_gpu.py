@@ -829,6 +829,36 @@ def test_superseded_workspace_stays_valid_for_captured_graphs(dev):
     assert np.abs(np_(xs.grad) - ref["grad"]).max() < 2e-6 * 64.0 / B
 
 
+def test_workspaces_grow_geometrically_and_can_be_released(dev):
+    """A loop whose sequences keep getting longer (length-bucketed batches) must not keep one superseded workspace per
+    new maximum: a superseding buffer is >= 1.5x its predecessor, so 50 rising shapes leave O(log) buffers; and
+    release_workspaces() gives everything back (eager code, no captured graph alive)."""
+    import ctc_amd
+    from ctc_amd import functional as F
+    ctc_amd.release_workspaces(dev)
+    B, C, S = 4, 24, 6
+    Ts = list(range(40, 540, 10))                            # blank-CTC: the workspace grows with T
+    for T in Ts:
+        lp, tgt, Tb, L = synth_blank(T, T, B, C, S)
+        x = lp.to(dev).requires_grad_(True)
+        loss, _ = ctc_amd.blank_ctc_loss(x, tgt.to(dev), Tb.to(dev), L.to(dev))
+        loss.backward()
+    torch.cuda.synchronize()
+    held = [w for (d, _s, v), ws in F._workspaces.items() if d == dev.index and v == 2 for w in ws]
+    sizes = [w.numel() for w in held]
+    assert 1 <= len(sizes) <= 9, sizes                       # log_1.5(need(530) / need(40)) + 1
+    assert all(b >= a + a // 2 for a, b in zip(sizes, sizes[1:])), sizes
+    assert sum(sizes) <= 3.2 * sizes[-1], sizes
+    # the last result is still right on the superseding buffer
+    ref = ctc_c.blank_ctc(np_(lp), np_(tgt), np_(Tb), np_(L), np.float64)
+    assert abs(float(loss) - float(ref["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+    freed = ctc_amd.release_workspaces(dev)
+    assert freed >= sum(sizes) and not any(d == dev.index for (d, _s, _v) in F._workspaces)
+    loss2, _ = ctc_amd.blank_ctc_loss(x.detach(), tgt.to(dev), Tb.to(dev), L.to(dev))     # allocates afresh
+    assert abs(float(loss2) - float(ref["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+    assert ctc_amd.workspace_status() == 0
+
+
 def test_blank_persistent_launch_beside_a_busy_stream(dev, monkeypatch):
     """The persistent blank-CTC launch (workgroups waiting for each other) while ANOTHER stream keeps the GPU
     busy with a long kernel: it may be delayed, it must not hang or return poisoned values."""
