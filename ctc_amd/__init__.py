@@ -9,8 +9,8 @@ from .functional import (CTCLoss, binary_best_path, binary_ctc_loss, binary_post
                          noblank_best_path, noblank_ctc_loss, noblank_posteriors, release_workspaces, set_blank_schedule,
                          workspace_status)
 from .modules import BlankCTC, NoBlankBinaryCTC, NoBlankCTC  # noqa: F401
-from .producer import LSTM_cell, lstm_cell_step, lstm_series  # noqa: F401
+from .producer import LSTM_cell, head_forward, lstm_cell_step, lstm_series  # noqa: F401
 
 __all__ = ["CTCLoss", "NoBlankCTC", "NoBlankBinaryCTC", "BlankCTC", "noblank_ctc_loss",
            "binary_ctc_loss", "blank_ctc_loss", "noblank_best_path", "noblank_posteriors", "CtcAmdError",
-           "workspace_status", "release_workspaces", "check_status", "set_blank_schedule", "dedup_multihot_targets", "collective_gate", "LSTM_cell", "lstm_cell_step", "lstm_series", "binary_posteriors", "binary_best_path"]
+           "workspace_status", "release_workspaces", "check_status", "set_blank_schedule", "dedup_multihot_targets", "collective_gate", "LSTM_cell", "head_forward", "lstm_cell_step", "lstm_series", "binary_posteriors", "binary_best_path"]

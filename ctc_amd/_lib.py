@@ -36,6 +36,8 @@ PROTOTYPES = {
     "ctc_amd_lstm_series": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int,
                                    _vp, _i64, _i64, _int, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ctc_amd_lstm_series_backward": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "ctc_amd_head_forward": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _int, _int, _int, _int,
+                                    _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ctc_amd_dedup_multihot_targets": (_int, [_vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ctc_amd_blank_set_schedule": (_int, [_int]),
     "ctc_amd_workspace_status": (_int, [_vp, _int, _vp, ctypes.POINTER(ctypes.c_uint)]),

@@ -360,3 +360,138 @@ extern "C" int ctc_amd_lstm_series_backward(const float *d_series, int64_t ds_st
     return launch<lstm_series_bwd_kernel>(dim3((B + kSeriesSamples - 1) / kSeriesSamples), dim3(kLstmThreads), smem,
                                           static_cast<hipStream_t>(stream), p);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The HEAD of the producer (LSTM.py:8-18, called per frame at :48): Linear(K -> C) + BatchNorm1d + ReLU +
+// Dropout for ALL frames in one launch.  One workgroup per (frame, tile of 16 output columns); wave m owns batch rows
+// 16 m .. 16 m + 15 (B <= 256 rows of one frame fit one workgroup, which is what BatchNorm's per-frame batch statistics
+// need: a column's mean and variance are taken over the B rows of ONE frame, as the reference's per-frame calls do).
+// The product runs on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32, an fmaf chain per output): a lane loads
+// 16 bytes of its feature row and 16 bytes of its weight row per four MFMAs -- the k index is permuted the same way on
+// both operands (lane (r, q) holds k = 16 kb + 4 q + i for MFMA i), which a sum over k does not see.
+// Train mode: batch statistics (two passes: mean, then the centred second moment, like torch), saved per (frame, column)
+// for the backward pass and for the running statistics, which the reference updates frame after frame (a closed form
+// over the T frames, applied by the caller).  Eval mode: the running statistics.  Dropout is a mask tensor the caller
+// hands in (already scaled by 1 / (1 - p)): the random stream stays torch's.
+struct HeadParams {
+    const float *feat;                                        // [T][B][K]
+    int64_t fst, fsb;
+    const float *w, *bias, *gamma, *beta;                    // Linear [C][K], [C]; BatchNorm weight / bias [C]
+    const float *rmean, *rvar;                               // eval mode: running statistics; NULL: batch statistics
+    const float *mask;                                       // [T][B][C] or NULL
+    float eps;
+    int T, B, K, C;
+    float *out;                                              // [T][B] rows of C at (ost, osb)
+    int64_t ost, osb;
+    float *lin, *smean, *svar, *sinv;                        // optional: Linear output [T][B][C]; batch mean / biased variance / 1/sqrt(var + eps) [T][C]
+};
+
+typedef float head_f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(1024) void head_kernel(HeadParams p)
+{
+    __shared__ float red[16][16];                            // [wave][column of the tile]
+    const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int NW = blockDim.x >> 6;
+    // operands: A row = batch row 16 w + fr, B row = output column 16 n + fr (clamped: the padding is masked out below)
+    const int arow = min(16 * w + fr, p.B - 1), bcol = min(16 * n + fr, p.C - 1);
+    const float *ap = p.feat + (int64_t)t * p.fst + (int64_t)arow * p.fsb + 4 * fq;
+    const float *bp = p.w + (int64_t)bcol * p.K + 4 * fq;
+    head_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int KB = p.K >> 4;                                 // K is a multiple of 16 (checked by the host)
+    typedef head_f4 head_f4u;                                // (rows are 16-byte aligned: checked by the host)
+    for (int kb = 0; kb < KB; kb += 2) {                     // two batches of four MFMAs in flight
+        const head_f4 a0 = *reinterpret_cast<const head_f4u *>(ap + 16 * kb), b0 = *reinterpret_cast<const head_f4u *>(bp + 16 * kb);
+        const bool two = kb + 1 < KB;
+        const head_f4 a1 = two ? *reinterpret_cast<const head_f4u *>(ap + 16 * kb + 16) : head_f4{0.f, 0.f, 0.f, 0.f};
+        const head_f4 b1 = two ? *reinterpret_cast<const head_f4u *>(bp + 16 * kb + 16) : head_f4{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
+    }
+    // acc[j] = Linear output (without bias) of batch row 16 w + 4 fq + j, column 16 n + fr
+    const int col = 16 * n + fr;
+    const bool colok = col < p.C;
+    const float bias = colok ? p.bias[col] : 0.f;
+    float x[4];
+    bool rowok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rowok[j] = 16 * w + 4 * fq + j < p.B;
+        x[j] = acc[j] + bias;
+    }
+    auto column_total = [&](float v) {                       // sum over the batch rows of the frame, every lane of a column gets it
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        __syncthreads();                                     // (the previous total has been read by everybody)
+        if (fq == 0) red[w][fr] = v;
+        __syncthreads();
+        float s = 0.f;
+        for (int i = 0; i < NW; ++i) s += red[i][fr];
+        return s;
+    };
+    float mean, inv;
+    if (p.rmean) {                                           // eval mode
+        mean = colok ? p.rmean[col] : 0.f;
+        inv = 1.0f / sqrtf((colok ? p.rvar[col] : 1.f) + p.eps);
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += rowok[j] ? x[j] : 0.f;
+        mean = column_total(s) / (float)p.B;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q += rowok[j] ? (x[j] - mean) * (x[j] - mean) : 0.f;
+        const float var = column_total(q) / (float)p.B;      // biased, what the normalisation uses
+        inv = 1.0f / sqrtf(var + p.eps);
+        if (w == 0 && fq == 0 && colok) {
+            if (p.smean) p.smean[(int64_t)t * p.C + col] = mean;
+            if (p.svar) p.svar[(int64_t)t * p.C + col] = var;
+            if (p.sinv) p.sinv[(int64_t)t * p.C + col] = inv;
+        }
+    }
+    const float g = colok ? p.gamma[col] : 0.f, be = colok ? p.beta[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = 16 * w + 4 * fq + j;
+        if (!rowok[j] || !colok) continue;
+        if (p.lin) p.lin[((int64_t)t * p.B + b) * p.C + col] = x[j];
+        float y = (x[j] - mean) * inv * g + be;
+        y = y > 0.f ? y : 0.f;
+        if (p.mask) y *= p.mask[((int64_t)t * p.B + b) * p.C + col];
+        p.out[(int64_t)t * p.ost + (int64_t)b * p.osb + col] = y;
+    }
+}
+
+extern "C" int ctc_amd_head_forward(const float *feat, int64_t feat_stride_t, int64_t feat_stride_b,
+                                    const float *weight, const float *bias, const float *bn_weight, const float *bn_bias,
+                                    const float *running_mean, const float *running_var, float eps, const float *mask,
+                                    int T, int B, int K, int C,
+                                    float *out, int64_t out_stride_t, int64_t out_stride_b,
+                                    float *linear_out, float *save_mean, float *save_var, float *save_invstd, void *stream)
+{
+    if (!feat || !weight || !bias || !bn_weight || !bn_bias || !out) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (T < 1 || B < 1 || K < 1 || C < 1 || (running_mean == nullptr) != (running_var == nullptr)) return CTC_AMD_ERR_BAD_ARGUMENT;
+    if (out_stride_b < C) return CTC_AMD_ERR_BAD_ARGUMENT;
+    // one workgroup holds the B rows of a frame (BatchNorm's statistics); 16-byte operand loads
+    if (B > 256 || (K & 15) != 0 || (feat_stride_b & 3) != 0 || (feat_stride_t & 3) != 0 ||
+        (reinterpret_cast<uintptr_t>(feat) & 15) != 0 || (reinterpret_cast<uintptr_t>(weight) & 15) != 0)
+        return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
+    if (running_mean == nullptr && B < 2) return CTC_AMD_ERR_BAD_ARGUMENT;       // (torch raises too: one value per channel)
+    HeadParams p;
+    p.feat = feat; p.fst = feat_stride_t; p.fsb = feat_stride_b;
+    p.w = weight; p.bias = bias; p.gamma = bn_weight; p.beta = bn_bias;
+    p.rmean = running_mean; p.rvar = running_var; p.mask = mask; p.eps = eps;
+    p.T = T; p.B = B; p.K = K; p.C = C;
+    p.out = out; p.ost = out_stride_t; p.osb = out_stride_b;
+    p.lin = linear_out; p.smean = save_mean; p.svar = save_var; p.sinv = save_invstd;
+    const int NW = (B + 15) / 16;
+    hipLaunchKernelGGL(head_kernel, dim3(T, (C + 15) / 16), dim3(64 * NW), 0, static_cast<hipStream_t>(stream), p);
+    return (int)hipGetLastError();
+}

@@ -1,9 +1,11 @@
 """The producer of the logits: drop-in for the reference's ``LSTM_cell`` (LSTM.py:21-51).
 
 ``LSTM_cell(args).forward(feat, v_hsn, v_csn)`` runs, per frame, ``v = self.v(feat[time])`` (Linear + BatchNorm1d +
-ReLU + Dropout: torch's own layers, kept) and one ``nn.LSTMCell`` step whose hidden state is stored as
-``v_series[time]`` -- the ``[T, B, C]`` tensor the CTC losses read.  Here the LSTMCell step and that store are ONE HIP
-launch per frame (``ctc_amd_lstm_cell_step``, include/ctc_amd.h): gate products, cell update, and the hidden state
+ReLU + Dropout) and one ``nn.LSTMCell`` step whose hidden state is stored as ``v_series[time]`` -- the ``[T, B, C]``
+tensor the CTC losses read.  Here the head of ALL frames is one HIP launch (``ctc_amd_head_forward``: the 1024 -> C
+product on the matrix cores, BatchNorm with the statistics of each frame's batch in train mode / the running statistics
+in eval mode, ReLU, and the dropout mask torch drew), and the LSTMCell steps and stores are one more
+(``ctc_amd_lstm_series``; one launch per frame, ``ctc_amd_lstm_cell_step``, at other sizes): gate products, cell update, and the hidden state
 written straight into the logits tensor, optionally with one pad column (``pad_classes=True``: an odd class count such
 as the reference's 33 gets rows of C + 1 floats, the extra logit -1e30 -- softmax gives it exactly 0, so no loss or
 gradient value changes, and the rows become the even, 8-byte aligned rows of the fastest loss kernel).
@@ -30,6 +32,87 @@ class BasicModule(nn.Module):
 
     def forward(self, x):
         return self.layers(x)
+
+
+def head_forward(feat, weight, bias, bn_weight, bn_bias, running_mean=None, running_var=None, eps=1e-5, mask=None,
+                 want_backward_state=False):
+    """``dropout(relu(batchnorm(feat[t] @ weight.T + bias)))`` for every frame t in ONE launch (``ctc_amd_head_forward``)
+    -> (out [T,B,C], lin [T,B,C] | None, mean [T,C] | None, var [T,C] | None, invstd [T,C] | None), or None when the launch
+    does not take the shape (B > 256, K not a multiple of 16, unaligned rows).  running_mean / running_var: eval mode;
+    both None: the statistics of each frame's batch.  ``mask``: [T,B,C], already scaled by 1 / (1 - p)."""
+    F._require_hip(feat, "feat")
+    T, B, K = feat.shape
+    C = weight.shape[0]
+    dev = feat.device
+    f = feat if (feat.dtype is torch.float32 and feat.stride(2) == 1) else feat.float().contiguous()
+    prm = [t if (t.dtype is torch.float32 and t.is_contiguous()) else t.float().contiguous()
+           for t in (weight, bias, bn_weight, bn_bias)]
+    rm = rv = None
+    if running_mean is not None:
+        rm, rv = running_mean.float().contiguous(), running_var.float().contiguous()
+    mk = None if mask is None else (mask if (mask.dtype is torch.float32 and mask.is_contiguous()) else mask.float().contiguous())
+    out = torch.empty((T, B, C), dtype=torch.float32, device=dev)
+    train = rm is None
+    lin = torch.empty((T, B, C), dtype=torch.float32, device=dev) if want_backward_state else None
+    mean = torch.empty((T, C), dtype=torch.float32, device=dev) if train else None
+    var = torch.empty((T, C), dtype=torch.float32, device=dev) if train else None
+    inv = torch.empty((T, C), dtype=torch.float32, device=dev) if train else None
+    ptr = lambda t: None if t is None else t.data_ptr()
+    with F._on_device(dev):
+        rc = _lib.load().ctc_amd_head_forward(f.data_ptr(), f.stride(0), f.stride(1), *(t.data_ptr() for t in prm), ptr(rm), ptr(rv),
+                                              float(eps), ptr(mk), T, B, K, C, out.data_ptr(), out.stride(0), out.stride(1),
+                                              ptr(lin), ptr(mean), ptr(var), ptr(inv), F._stream_handle(dev))
+    if rc == _lib.ERR_UNSUPPORTED_SHAPE:
+        return None
+    if rc:
+        _lib.check(rc, "ctc_amd_head_forward")
+    return out, lin, mean, var, inv
+
+
+class _HeadFn(torch.autograd.Function):
+    """feat [T,B,K], Linear and BatchNorm parameters, running statistics (eval) or None (train), mask -> the head's output
+    [T,B,C] (+ the batch statistics, non-differentiable).  Forward: one HIP launch.  Backward: elementwise torch arithmetic on
+    the saved Linear output and statistics (BatchNorm's own formulas) and two GEMMs over all frames at once."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, bn_weight, bn_bias, running_mean, running_var, eps, mask):
+        need = any(ctx.needs_input_grad[:5])
+        res = head_forward(feat, weight, bias, bn_weight, bn_bias, running_mean, running_var, eps, mask, want_backward_state=need)
+        if res is None:
+            raise _lib.CtcAmdError("ctc_amd: the fused head does not take this shape (B <= 256, feature dimension a multiple of 16)")
+        out, lin, mean, var, inv = res
+        ctx.train = running_mean is None
+        ctx.eps = float(eps)
+        if need:
+            if not ctx.train:
+                mean, inv = running_mean.float().unsqueeze(0), torch.rsqrt(running_var.float() + float(eps)).unsqueeze(0)
+            ctx.save_for_backward(feat, weight, bn_weight, bn_bias, lin, mean, inv, mask)
+        stats = (mean, var) if ctx.train else (None, None)
+        if ctx.train:
+            ctx.mark_non_differentiable(mean, var)
+        return (out,) + stats
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out, _dm=None, _dv=None):
+        feat, weight, gamma, beta, lin, mean, inv, mask = ctx.saved_tensors
+        T, B, C = lin.shape
+        xhat = (lin - mean.unsqueeze(1)) * inv.unsqueeze(1)
+        dy = d_out.float()
+        if mask is not None:
+            dy = dy * mask
+        dy = dy * ((xhat * gamma + beta) > 0)
+        dbeta = dy.sum((0, 1))
+        dgamma = (dy * xhat).sum((0, 1))
+        dxh = dy * gamma
+        if ctx.train:                                        # BatchNorm over the B rows of each frame
+            dlin = inv.unsqueeze(1) * (dxh - dxh.mean(1, keepdim=True) - xhat * (dxh * xhat).mean(1, keepdim=True))
+        else:
+            dlin = dxh * inv.unsqueeze(1)
+        flat = dlin.reshape(T * B, C)
+        dW = flat.t() @ feat.reshape(T * B, -1).float()
+        dfeat = (flat @ weight.float()).reshape(feat.shape) if ctx.needs_input_grad[0] else None
+        return dfeat, dW, flat.sum(0), dgamma, dbeta, None, None, None, None
 
 
 def lstm_cell_step(x, h, c, w_ih, w_hh, b_ih, b_hh, series_row=None, pad_value=PAD_LOGIT, want_gates=False):
@@ -183,9 +266,38 @@ class LSTM_cell(nn.Module):
         self.v = _BaseModule(self.input_size, self.v_class)
         self.v_cell = nn.LSTMCell(self.v_class, self.v_class)
 
+    def _head(self, feat):
+        """self.v applied to every frame (LSTM.py:48): one launch when self.v is the reference's BasicModule and the shape
+        is one the launch takes, the module itself frame by frame otherwise (a custom _BaseModule, B > 256, ...)."""
+        T = self.temporal
+        layers = getattr(self.v, "layers", None)
+        std = (isinstance(layers, nn.Sequential) and len(layers) == 4 and isinstance(layers[0], nn.Linear)
+               and isinstance(layers[1], nn.BatchNorm1d) and isinstance(layers[2], nn.ReLU) and isinstance(layers[3], nn.Dropout)
+               and layers[0].bias is not None and layers[1].affine and layers[1].track_running_stats)
+        B, K = feat.shape[1], feat.shape[2]
+        if not std or feat.shape[0] < T or B > 256 or K % 16 or (self.training and (B < 2 or layers[1].momentum is None)):
+            return torch.stack([self.v(feat[time]) for time in range(T)])
+        lin, bn, drop = layers[0], layers[1], layers[3]
+        x = feat[:T]
+        mask = None
+        if self.training and drop.p > 0:                     # torch draws the mask (its Philox stream), one call for all frames
+            mask = torch.nn.functional.dropout(torch.ones((T, B, lin.out_features), dtype=torch.float32, device=feat.device),
+                                               drop.p, True)
+        if not self.training:
+            return _HeadFn.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mask)[0]
+        out, mean, var = _HeadFn.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, None, None, bn.eps, mask)
+        with torch.no_grad():                                # the running statistics, as T per-frame calls would leave them
+            m = float(bn.momentum)
+            coef = m * (1.0 - m) ** torch.arange(T - 1, -1, -1, dtype=torch.float32, device=feat.device)
+            keep = (1.0 - m) ** T
+            bn.running_mean.mul_(keep).add_(coef @ mean)
+            bn.running_var.mul_(keep).add_(coef @ (var * (B / (B - 1.0))))
+            bn.num_batches_tracked += T
+        return out
+
     def forward(self, feat, v_hsn, v_csn):
         F._require_hip(feat, "feat")
-        v_all = torch.stack([self.v(feat[time]) for time in range(self.temporal)])   # (BatchNorm statistics per frame, as the reference)
+        v_all = self._head(feat)                             # (BatchNorm statistics per frame, as the reference)
         H = self.v_class
         cols = H + 1 if (self.pad_classes and H % 2) else H
         cell = self.v_cell

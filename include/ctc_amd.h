@@ -258,6 +258,26 @@ int ctc_amd_lstm_series_backward(const float *d_series, int64_t ds_stride_t, int
                                  const float *gates, const float *cells, const float *w_hh,
                                  int T, int B, int H, float *dpre_out, float *dh0_out, float *dc0_out, void *stream);
 
+/* The HEAD of the producer (LSTM.py:8-18 `nn.Linear(inDim, outDim) -> nn.BatchNorm1d -> nn.ReLU -> nn.Dropout`,
+ * called once per frame at LSTM.py:48) for all T frames as ONE launch: out[t] = dropout(relu(batchnorm(feat[t] W^T + b))).
+ *   feat: row (t, b) of K floats at feat + t * feat_stride_t + b * feat_stride_b (16-byte aligned rows, K a multiple of 16);
+ *   weight [C,K], bias [C]: the Linear layer;  bn_weight, bn_bias [C]: BatchNorm1d's affine parameters;
+ *   running_mean / running_var [C]: eval mode (BatchNorm on its running statistics); both NULL: train mode -- the
+ *   statistics of each FRAME's batch of B rows (biased variance, eps inside the square root), as the reference's per-frame
+ *   calls compute them (B <= 256: one workgroup holds a frame's rows; B >= 2);
+ *   mask [T,B,C] or NULL: the dropout mask, already scaled by 1 / (1 - p) (the caller draws it: the random stream stays
+ *   the framework's);  out: row (t, b) of C floats at out + t * out_stride_t + b * out_stride_b;
+ *   linear_out [T,B,C], save_mean / save_var / save_invstd [T,C] or NULL: what a backward pass and the update of the
+ *   running statistics need (train mode; running = (1 - m) running + m stat, frame after frame, var unbiased: the caller).
+ * The product is exact fp32 on the matrix cores (an fmaf chain per output; the order of the sum over k differs from a
+ * BLAS GEMM's: results agree with torch's layers to ~1e-6 relative). */
+int ctc_amd_head_forward(const float *feat, int64_t feat_stride_t, int64_t feat_stride_b,
+                         const float *weight, const float *bias, const float *bn_weight, const float *bn_bias,
+                         const float *running_mean, const float *running_var, float eps, const float *mask,
+                         int T, int B, int K, int C,
+                         float *out, int64_t out_stride_t, int64_t out_stride_b,
+                         float *linear_out, float *save_mean, float *save_var, float *save_invstd, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -303,13 +303,71 @@ def F7(NB, NBB):
          v_series=v_series.numpy(), c_final=c.numpy(), torch_version=np.array(torch.__version__))
 
 
+def F8(NB, NBB):
+    """the head of the producer in TRAIN mode (LSTM.py:8-18,46-50): the reference's own LSTM_cell, BatchNorm on
+    the statistics of each frame's batch (and its running statistics updated frame after frame), Dropout p = 0 and p = 0.3
+    with the masks it drew captured by a forward hook.  Stored: inputs, parameters, masks, the head's per-frame outputs,
+    v_series, the running statistics afterwards, and the reference's autograd gradients of sum(v_series * R)."""
+    import types
+    from LSTM import LSTM_cell
+    torch.manual_seed(8)
+    args = types.SimpleNamespace(extract_feat_dim=1024, v_class=33, batch_size=10, temporal=6)
+    model = LSTM_cell(args).train()
+    lin, bn, drop = model.v.layers[0], model.v.layers[1], model.v.layers[3]
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0.0, 0.2)
+        bn.running_mean.normal_(0.0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    feat = torch.randn(args.temporal, args.batch_size, 1024)
+    h0, c0 = 0.1 * torch.randn(args.batch_size, 33), 0.1 * torch.randn(args.batch_size, 33)
+    R = torch.randn(args.temporal, args.batch_size, 33)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    arrs = dict(feat=feat.numpy(), h0=h0.numpy(), c0=c0.numpy(), R=R.numpy(), lin_w=lin.weight.detach().numpy(),
+                lin_b=lin.bias.detach().numpy(), bn_w=bn.weight.detach().numpy(), bn_b=bn.bias.detach().numpy(),
+                rm0=rm0.numpy(), rv0=rv0.numpy(), eps=np.array(bn.eps), momentum=np.array(bn.momentum),
+                torch_version=np.array(torch.__version__))
+    cell = model.v_cell
+    arrs.update(w_ih=cell.weight_ih.detach().numpy(), w_hh=cell.weight_hh.detach().numpy(),
+                b_ih=cell.bias_ih.detach().numpy(), b_hh=cell.bias_hh.detach().numpy())
+    for tag, p in (("p0", 0.0), ("p3", 0.3)):
+        drop.p = p
+        with torch.no_grad():
+            bn.running_mean.copy_(rm0)
+            bn.running_var.copy_(rv0)
+            bn.num_batches_tracked.zero_()
+        masks, heads = [], []
+
+        def hook(_m, inp, out):
+            x = inp[0].detach()
+            masks.append(torch.where(x > 0, out.detach() / x.clamp_min(1e-30), torch.zeros_like(x)))
+            heads.append(out.detach().clone())
+        hd = drop.register_forward_hook(hook)
+        torch.manual_seed(80)
+        f = feat.clone().requires_grad_(True)
+        for prm in model.parameters():
+            prm.grad = None
+        v_series = model(f, h0, c0)
+        (v_series * R).sum().backward()
+        hd.remove()
+        arrs.update({"mask_" + tag: torch.stack(masks).numpy(), "head_" + tag: torch.stack(heads).numpy(),
+                     "v_series_" + tag: v_series.detach().numpy(), "rm_" + tag: bn.running_mean.numpy().copy(),
+                     "rv_" + tag: bn.running_var.numpy().copy(), "nbt_" + tag: np.array(int(bn.num_batches_tracked)),
+                     "d_feat_" + tag: f.grad.numpy(), "d_lin_w_" + tag: lin.weight.grad.numpy().copy(),
+                     "d_lin_b_" + tag: lin.bias.grad.numpy().copy(), "d_bn_w_" + tag: bn.weight.grad.numpy().copy(),
+                     "d_bn_b_" + tag: bn.bias.grad.numpy().copy(), "d_w_ih_" + tag: cell.weight_ih.grad.numpy().copy()})
+        print("  %s: kept %.3f of the activations, |v_series| max %.3f" % (tag, float((torch.stack(masks) > 0).float().mean()),
+                                                                           float(v_series.abs().max())))
+    save("lstm_head_train", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     if sys.argv[1:] == ["F6"]:                                # needs torch only, not the reference's modules
         F6(None, None)
         sys.exit(0)
     NB, NBB = _import_reference()
-    which = sys.argv[1:] or ["F1", "F2", "F3", "F4", "F5", "F6", "F7"]
+    which = sys.argv[1:] or ["F1", "F2", "F3", "F4", "F5", "F6", "F7", "F8"]
     for w in which:
         print(w)
         globals()[w](NB, NBB)

@@ -209,3 +209,117 @@ def test_lstm_series_backward_one_launch_matches_torch_autograd(dev, shape):
     for a, b_, what in zip(out["hip"], want, names):
         scale = max(1.0, float(np.abs(b_).max()))
         assert np.abs(a - b_).max() <= 2e-5 * scale, (what, shape, np.abs(a - b_).max())
+
+
+# ------------------------------------------------------------------ the head: Linear + BatchNorm1d + ReLU + Dropout (LSTM.py:8-18)
+def _reference_args(temporal):
+    import types
+    return types.SimpleNamespace(extract_feat_dim=1024, v_class=33, batch_size=10, temporal=temporal)
+
+
+def _load_head_state(model, d, dev):
+    lin, bn = model.v.layers[0], model.v.layers[1]
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(d["lin_w"])); lin.bias.copy_(torch.from_numpy(d["lin_b"]))
+        bn.weight.copy_(torch.from_numpy(d["bn_w"])); bn.bias.copy_(torch.from_numpy(d["bn_b"]))
+        bn.running_mean.copy_(torch.from_numpy(d["rm0"])); bn.running_var.copy_(torch.from_numpy(d["rv0"]))
+        bn.num_batches_tracked.zero_()
+        c = model.v_cell
+        c.weight_ih.copy_(torch.from_numpy(d["w_ih"])); c.weight_hh.copy_(torch.from_numpy(d["w_hh"]))
+        c.bias_ih.copy_(torch.from_numpy(d["b_ih"])); c.bias_hh.copy_(torch.from_numpy(d["b_hh"]))
+    return model.to(dev)
+
+
+@pytest.mark.parametrize("tag", ["p0", "p3"])
+def test_head_train_mode_golden(dev, golden, monkeypatch, tag):
+    """The fused head against the reference's OWN LSTM_cell in TRAIN mode (tests/golden/lstm_head_train.npz, make_golden.py
+    F8): BatchNorm on each frame's batch statistics, the dropout masks the reference drew (p = 0 and p = 0.3), the running
+    statistics after six frames, and the reference's autograd gradient of every parameter and of the features."""
+    import ctc_amd
+    d = golden("lstm_head_train")
+    T = d["feat"].shape[0]
+    model = _load_head_state(ctc_amd.LSTM_cell(_reference_args(T)), d, dev).train()
+    model.v.layers[3].p = 0.0 if tag == "p0" else 0.3
+    mask = torch.from_numpy(d["mask_" + tag]).to(dev)
+    if tag == "p3":                                          # the mask the reference drew stands in for torch's draw
+        monkeypatch.setattr(torch.nn.functional, "dropout", lambda x, p, training: mask)
+    feat = torch.from_numpy(d["feat"]).to(dev).requires_grad_(True)
+    h0, c0, R = (torch.from_numpy(d[k]).to(dev) for k in ("h0", "c0", "R"))
+    # the head alone, through the C ABI
+    lin, bn = model.v.layers[0], model.v.layers[1]
+    out, _lin, mean, var, inv = ctc_amd.head_forward(feat.detach(), lin.weight, lin.bias, bn.weight, bn.bias, eps=bn.eps,
+                                                     mask=mask if tag == "p3" else None, want_backward_state=True)
+    assert np.abs(np_(out) - d["head_" + tag]).max() < 2e-5
+    # the module: v_series, running statistics, every gradient
+    v_series = model(feat, h0, c0)
+    assert np.abs(np_(v_series) - d["v_series_" + tag]).max() < 1e-5
+    assert np.abs(np_(bn.running_mean) - d["rm_" + tag]).max() < 1e-5 and np.abs(np_(bn.running_var) - d["rv_" + tag]).max() < 1e-5
+    assert int(bn.num_batches_tracked) == int(d["nbt_" + tag]) == T
+    (v_series * R).sum().backward()
+    got = {"d_feat": feat.grad, "d_lin_w": lin.weight.grad, "d_lin_b": lin.bias.grad, "d_bn_w": bn.weight.grad,
+           "d_bn_b": bn.bias.grad, "d_w_ih": model.v_cell.weight_ih.grad}
+    for k, g in got.items():
+        want = d[k + "_" + tag]
+        # (d_lin_b is rounding noise on both sides: batch statistics remove a per-column constant)
+        scale = max(0.05, float(np.abs(want).max()))
+        assert np.abs(np_(g) - want).max() <= 2e-4 * scale, (k, tag, np.abs(np_(g) - want).max(), scale)
+
+
+@pytest.mark.parametrize("shape", [(5, 10, 1024, 33), (3, 256, 1024, 158), (4, 37, 64, 40), (2, 2, 16, 5)])
+@pytest.mark.parametrize("train", [True, False])
+def test_head_matches_torch_layers_forward_and_backward(dev, shape, train):
+    """ctc_amd_head_forward + its backward against torch's own nn.Linear / nn.BatchNorm1d / nn.ReLU applied frame by frame
+    on the device (train: batch statistics and the running-statistics update; eval: running statistics), with a dropout mask."""
+    from ctc_amd import producer
+    T, B, K, C = shape
+    g = torch.Generator().manual_seed(sum(shape) + int(train))
+    rnd = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)          # noqa: E731
+    lin, bn = torch.nn.Linear(K, C).to(dev), torch.nn.BatchNorm1d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(C) * 0.5 + 1.0); bn.bias.copy_(rnd(C) * 0.2)
+        bn.running_mean.copy_(rnd(C) * 0.3); bn.running_var.copy_(rnd(C) * 0.4 + 1.0)
+    bn.train(train)
+    mask = ((rnd(T, B, C) > -0.4).float() / 0.7)
+    up = rnd(T, B, C)
+    leaves = rnd(T, B, K)
+    res = {}
+    for name in ("torch", "hip"):
+        feat = leaves.clone().requires_grad_(True)
+        lin.zero_grad(); bn.zero_grad()
+        rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+        if name == "torch":
+            out = torch.stack([torch.relu(bn(lin(feat[t]))) for t in range(T)]) * mask
+        else:
+            if train:
+                out, mean, var = producer._HeadFn.apply(feat, lin.weight, lin.bias, bn.weight, bn.bias, None, None, bn.eps, mask)
+                assert mean.shape == (T, C) and not mean.requires_grad
+            else:
+                out = producer._HeadFn.apply(feat, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mask)[0]
+        (out * up).sum().backward()
+        res[name] = [np_(out)] + [np_(t.grad) for t in (feat, lin.weight, lin.bias, bn.weight, bn.bias)]
+        if name == "torch":                                  # (the layers updated their running statistics: put them back)
+            with torch.no_grad():
+                bn.running_mean.copy_(rm0); bn.running_var.copy_(rv0)
+    for a, b_, what in zip(res["hip"], res["torch"], ("out", "d_feat", "d_W", "d_b", "d_gamma", "d_beta")):
+        if train and what == "d_b":                          # identically 0 under batch statistics: rounding noise on both sides,
+            continue                                         # amplified by 1 / sqrt(var) when a column's two rows nearly agree
+        scale = max(1.0, float(np.abs(b_).max()))
+        assert np.abs(a - b_).max() <= 1e-4 * scale, (what, shape, train, np.abs(a - b_).max(), scale)
+
+
+def test_head_shapes_the_launch_does_not_take_fall_back_to_the_layers(dev):
+    """B > 256 or a feature dimension that is not a multiple of 16: CTC_AMD_ERR_UNSUPPORTED_SHAPE -> head_forward returns None
+    and LSTM_cell applies self.v frame by frame (as it does for any head that is not the reference's BasicModule)."""
+    import ctc_amd
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)          # noqa: E731
+    w, b_, gm, bt = rnd(8, 24), rnd(8), rnd(8), rnd(8)
+    assert ctc_amd.head_forward(rnd(2, 4, 24), w, b_, gm, bt) is None                   # K % 16
+    assert ctc_amd.head_forward(rnd(2, 300, 32), rnd(8, 32), b_, gm, bt) is None        # B > 256
+    import types
+    args = types.SimpleNamespace(extract_feat_dim=24, v_class=8, batch_size=4, temporal=3)
+    model = ctc_amd.LSTM_cell(args).to(dev).eval()
+    ref = torch.stack([model.v(x) for x in rnd(3, 4, 24)])
+    assert ref.shape == (3, 4, 8)
+    out = model(rnd(3, 4, 24), rnd(4, 8), rnd(4, 8))
+    assert out.shape == (3, 4, 8) and bool(torch.isfinite(out).all())
