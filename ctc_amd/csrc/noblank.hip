@@ -637,6 +637,23 @@ extern "C" int ctc_amd_noblank_posteriors(const float *x, int64_t stride_t, int6
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int ch = C <= 256 ? (C + kWave - 1) / kWave : 0;    // phase-serial kernel: any supported shape
+    {   // the four-rows-per-wave kernel of the loss (noblank_r16.hpp) wherever it takes the shape: same chains, the
+        // gradient phase cut off after the row-normalised posteriors
+        int n4 = 0, n2 = 0;
+        const bool aligned = C % 2 == 0 && stride_t % 2 == 0 && stride_b % 2 == 0 && reinterpret_cast<uintptr_t>(x) % 8 == 0;
+        const size_t rsmem = r16_smem_bytes(T, p.SP, C);
+        if (K == 1 && T <= kPipeMaxT && !p.lattice && aligned && r16_shape(C, n4, n2) && p.SP <= 31 && rsmem <= kMaxLds) {
+            const dim3 grid(B), block(kThreads);
+#define CTC_R16_CASE(K, A, Bq) case K: return launch<noblank_r16_kernel<A, Bq, false>>(grid, block, rsmem, s, p);
+            switch (4 * n4 + n2) {
+                CTC_R16_CASE(1, 0, 1) CTC_R16_CASE(2, 0, 2) CTC_R16_CASE(4, 1, 0) CTC_R16_CASE(5, 1, 1)
+                CTC_R16_CASE(6, 1, 2) CTC_R16_CASE(8, 2, 0) CTC_R16_CASE(9, 2, 1) CTC_R16_CASE(10, 2, 2)
+                CTC_R16_CASE(12, 3, 0) CTC_R16_CASE(13, 3, 1) CTC_R16_CASE(14, 3, 2)
+                default: return launch<noblank_r16_kernel<4, 0, false>>(grid, block, rsmem, s, p);
+            }
+#undef CTC_R16_CASE
+        }
+    }
     switch (K) {
         case 1: return launch_noblank<1>(ch, smem, s, p);
         case 2: return launch_noblank<2>(ch, smem, s, p);

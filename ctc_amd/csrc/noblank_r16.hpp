@@ -578,6 +578,11 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             for (int g = 0; g < G; ++g)
                 if (tv[g] >= 0) Row::template store_zero<NT>(p.grad + ((int64_t)tv[g] * p.B + b) * p.C, i16, col_ok);
         }
+        if (u >= 0 && p.gamma) {                              // posteriors of a sample without alignment: zeros
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                for (int l = i16; l < p.S && tv[g] >= 0; l += 16) p.gamma[((int64_t)b * p.T + tv[g]) * p.S + l] = 0.f;
+        }
         return;
     }
     typedef const volatile __attribute__((address_space(3))) int lds_cvint;
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
                     o[1] = __builtin_amdgcn_s_memrealtime();
                 }
             }
-        } else if (p.grad) {
+        } else if (p.grad || p.gamma) {
             r16_chain<false>(p, sm, p.T, Tb, L, p.SP);
             stamp(p, 11);
         }
@@ -756,7 +761,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         typedef const float __attribute__((address_space(1))) gfloat;
         if (t < p.T) prefetched = *(gfloat *)(row_ptr(p, t, nb) + (c < p.C ? c : p.C - 1));
     }
-    if (!p.grad) return;
+    if (!p.grad && !p.gamma) return;
 
     const int Tlive = Tb;
     const float gsc = p.grad_scale;
@@ -827,6 +832,13 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         for (int s = 0; s < 2; ++s) z[s] = __builtin_amdgcn_ldexpf(pr[s], ks[s] - kref);
         float tot = z[0] + z[1];
         row16_allsum(tot);
+        if (p.gamma) {                                       // (wave-uniform) ctc_amd_noblank_posteriors: gamma[b][t][l] instead of a gradient
+            const float ginv = (live && tot > 0.f) ? __builtin_amdgcn_rcpf(tot) : 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (t >= 0 && lst[s] < p.S) p.gamma[((int64_t)b * p.T + t) * p.S + lst[s]] = own[s] ? z[s] * ginv : 0.f;
+            continue;
+        }
         // (smoothed: grad = (1 - b) softmax - a occupancy - b, all times 1/B on live rows)
         float rinv = (live && tot > 0.f) ? gsc * p.ls_a * __builtin_amdgcn_rcpf(tot) : 0.f;
         if (starved) {                                       // never observed; loud if a hand-off were broken

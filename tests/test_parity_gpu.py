@@ -658,8 +658,11 @@ def test_autograd_path_is_graph_capturable(dev):
     assert np.abs(np_(xs.grad) - ref["grad"]).max() < 2e-6 * 32
 
 
-@pytest.mark.parametrize("shape", [(20, 4, 10, 5), (150, 8, 158, 20), (40, 3, 300, 70)])
+@pytest.mark.parametrize("shape", [(20, 4, 10, 5), (150, 8, 158, 20), (40, 3, 300, 70), (168, 5, 64, 31), (61, 300, 34, 9),
+                                   (50, 6, 33, 12)])
 def test_noblank_posteriors(dev, shape):
+    """gamma out of the loss kernel's own chains (the four-rows-per-wave kernel where it takes the shape -- the first, second,
+    fourth and fifth case --, the phase-serial kernel otherwise: C > 256, odd C)"""
     import ctc_amd
     T, B, C, S = shape
     x, lab, Tb, L = synth_noblank(sum(shape) + 3, T, B, C, S, var_T=True)
