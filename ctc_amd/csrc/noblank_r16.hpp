@@ -446,8 +446,8 @@ struct R16Row {
 #pragma unroll
         for (int k = 0; k < N2; ++k) *reinterpret_cast<f2_t *>(trow + off2(k, i16)) = z2;
     }
-    // grad row = x * rs - occupancy (from the tile), written through; `g` = start of the row in grad
-    // (`cb`: a constant added to every element -- the label-smoothing term, 0 otherwise; LS selects the form)
+    // grad row = x * rs + tile, the tile holding MINUS the class occupancy (nothing to negate here), written through;
+    // `g` = start of the row in grad (`cb`: a constant added to every element -- the label-smoothing term, 0 otherwise)
     template <bool NT, bool LS>
     __device__ __forceinline__ void store_grad(float *g, const float *trow, int i16, float rs, bool col_ok, float cb) const
     {
@@ -456,17 +456,17 @@ struct R16Row {
         for (int j = 0; j < N4; ++j) {
             const f4_t o = *reinterpret_cast<const f4_t *>(trow + off4(j, i16));
             f2_t olo = {o.x, o.y}, ohi = {o.z, o.w};
-            if (LS) { olo -= cb2; ohi -= cb2; }
+            if (LS) { olo += cb2; ohi += cb2; }
             const f2_t xlo = {a[j].x, a[j].y}, xhi = {a[j].z, a[j].w};
-            const f2_t vlo = __builtin_elementwise_fma(xlo, r2, -olo), vhi = __builtin_elementwise_fma(xhi, r2, -ohi);
+            const f2_t vlo = __builtin_elementwise_fma(xlo, r2, olo), vhi = __builtin_elementwise_fma(xhi, r2, ohi);
             const f4_t v = {vlo.x, vlo.y, vhi.x, vhi.y};
             if (!(kLast4 && j == N4 - 1) || col_ok) grad_store<NT>(reinterpret_cast<f4_t *>(g + off4(j, i16)), v);
         }
 #pragma unroll
         for (int k = 0; k < N2; ++k) {
             f2_t o = *reinterpret_cast<const f2_t *>(trow + off2(k, i16));
-            if (LS) o -= cb2;
-            const f2_t v = __builtin_elementwise_fma(c[k], r2, -o);
+            if (LS) o += cb2;
+            const f2_t v = __builtin_elementwise_fma(c[k], r2, o);
             if (k < N2 - 1 || col_ok) grad_store<NT>(reinterpret_cast<f2_t *>(g + off2(k, i16)), v);
         }
     }
@@ -561,6 +561,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     for (int i = tid; i < (p.SP + 1) * sm.TP; i += kThreads) sm.em[i - kR16Pad] = zero;   // pads + spare row
     if (tid < 16) sm.cnt[tid] = 0;
     if (tid == 16) *sm.done = 0;
+    if (tid == 17) sm.occ[((p.SP + 3) & ~3) + 1] = 0;
     if (tid < 8) sm.dummy[tid] = 0.f;
     // LDS-only barrier: __syncthreads() would also wait for every row load of the wave (s_waitcnt
     // vmcnt(0)), but a worker only needs its first group's rows to start
@@ -591,24 +592,6 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     if (u < 0) {
         __builtin_amdgcn_s_setprio(3);                       // the chains are the critical path
         if (w == 0) {
-            // while the first rows are on their way: occurrence index of every state among equal
-            // labels (0 = first).  Repeated labels add up in the workers' occupancy tiles, one
-            // plain read-modify-write pass per repetition (P3); the table is ordered before the
-            // chain's first progress count, which every worker awaits before it reads it.
-            if (p.grad) {
-                const int kl = lane < p.SP ? sm.lab[lane] : -1;
-                int oc = 0;
-                for (int l2 = 0; l2 < L; ++l2) {
-                    const int q = __builtin_amdgcn_readlane(kl, l2);
-                    oc += (l2 < lane && q == kl) ? 1 : 0;
-                }
-                if (lane >= L) oc = 0;
-                int mo = 0;
-                while (__builtin_amdgcn_ballot_w64(oc > mo) != 0) ++mo;
-                if (lane < p.SP) sm.occ[lane] = oc;
-                sm.occ[(p.SP + 3) & ~3] = mo;
-                lds_order();
-            }
             const cell_t a = r16_chain<true>(p, sm, p.T, Tb, L, p.SP);
             stamp(p, 11);
             // nll = -log alpha[T_b-1, L_b-1] (NoBlankCTC.py:58-68,139).  The chains ran on emissions that lack a
@@ -746,6 +729,24 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     lds_order();
     if (lane == 0) __hip_atomic_fetch_add(sm.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     stamp(p, 2);
+    // Occurrence index of every state among equal labels (0 = first): repeated labels add up in the workers' occupancy
+    // tiles, one plain read-modify-write pass per repetition (P3).  The last worker makes the table here, while the
+    // chains run -- it used to sit in front of the alpha chain, which therefore started (and ended) 0.3 us behind beta.
+    if (u == kPipeWorkers - 1 && p.grad) {
+        const int kl = lane < p.SP ? sm.lab[lane] : -1;
+        int oc = 0;
+        for (int l2 = 0; l2 < L; ++l2) {
+            const int q = __builtin_amdgcn_readlane(kl, l2);
+            oc += (l2 < lane && q == kl) ? 1 : 0;
+        }
+        if (lane >= L) oc = 0;
+        int mo = 0;
+        while (__builtin_amdgcn_ballot_w64(oc > mo) != 0) ++mo;
+        if (lane < p.SP) sm.occ[lane] = oc;
+        sm.occ[(p.SP + 3) & ~3] = mo;
+        lds_order();
+        sm.occ[((p.SP + 3) & ~3) + 1] = 1;                   // the table is there
+    }
     // More samples than CUs: the workgroup that follows this one on the CU (dispatch order: block + one full
     // round of CUs, the same XCD under round-robin placement -- speed only) will want the rows of ITS sample.
     // One 4-byte load per lane, one 128-byte line each, pulls that sample into this XCD's L2 while the chains
@@ -765,15 +766,16 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 
     const int Tlive = Tb;
     const float gsc = p.grad_scale;
+    Row::zero_tile(trow, i16);                               // the occupancy tile starts all zero and every group leaves it so
+    lds_order();
     bool starved = false;
-    const cell_t *const zero_r = sm.em + (size_t)p.SP * sm.TP;   // the spare state row of em stays zero
 
     // P3: middle-out, one look at the chains' progress per group
     // Every live row has the SAME total sum_l alpha_t(l) beta_t(l) (the sample's likelihood), so the exponent
     // that brings a row's terms into range need not be the row's own maximum: a lane keeps the one of the first
     // live row it meets (`kref`) and the later groups skip that reduction.
     int kref = 0;
-    bool have_ref = false;
+    bool have_ref = false, occ_seen = false;
 #pragma unroll
     for (int g = G - 1; g >= 0; --g) {
         if (!grp[g]) continue;
@@ -800,7 +802,16 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         if (CTC_DIAG(p) < 0) stamp(p, 3 + (G - 1 - g));
         if (g == G - 1) asm volatile("" ::"v"(prefetched));    // the prefetched value is "used" here (and dropped)
         int occn[2] = {0, 0}, max_occ = 0;
-        if (need_a > 0) {                                    // (wave-uniform; a group without live rows adds nothing)
+        if (need_a > 0 && !occ_seen && p.grad) {             // (once per wave; the table was made long before the chains cross)
+            int spins = 0;
+            while (*(lds_cvint *)(sm.occ + ((p.SP + 3) & ~3) + 1) == 0) {
+                if (++spins >= kSpinLimit) { starved = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            lds_order();
+            occ_seen = true;
+        }
+        if (need_a > 0 && p.grad) {                          // (wave-uniform; a group without live rows adds nothing)
             occn[0] = own[0] ? sm.occ[lst[0]] : 0;
             occn[1] = own[1] ? sm.occ[lst[1]] : 0;
             max_occ = __builtin_amdgcn_readfirstlane(sm.occ[(p.SP + 3) & ~3]);
@@ -816,9 +827,8 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bool in = live && own[s];
-            const int off = lst[s] * sm.TP + t;
-            const cell_t a = *(in ? sm.al + off : zero_r), bb = *(in ? sm.be + off : zero_r);
-            const cell_t e = *(in ? sm.em + off : zero_r);
+            const int off = (lst[s] < p.SP ? lst[s] : p.SP) * sm.TP + (t > 0 ? t : 0);   // a valid address, masked afterwards
+            const cell_t a = sm.al[off], bb = sm.be[off], e = sm.em[off];
             pr[s] = in ? a.x * bb.x * __builtin_amdgcn_rcpf(e.x) : 0.f;
             ks[s] = cell_k(a) + cell_k(bb) - cell_k(e);
         }
@@ -840,14 +850,12 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             continue;
         }
         // (smoothed: grad = (1 - b) softmax - a occupancy - b, all times 1/B on live rows)
-        float rinv = (live && tot > 0.f) ? gsc * p.ls_a * __builtin_amdgcn_rcpf(tot) : 0.f;
+        float rinv = (live && tot > 0.f) ? -gsc * p.ls_a * __builtin_amdgcn_rcpf(tot) : 0.f;   // (the tile holds MINUS the occupancy)
         if (starved) {                                       // never observed; loud if a hand-off were broken
             rinv = __builtin_nanf("");
             raise_status(p.counter, kStatusNoblankStarved);
         }
-        // class occupancy of the four rows: zero the tile, scatter the scaled posteriors
-        Row::zero_tile(trow, i16);
-        lds_order();
+        // MINUS the class occupancy of the four rows, scattered into the all-zero tile
         // (only lanes that own a state write; pass k adds the k-th repetition of a label)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -865,6 +873,12 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             if (smooth) x.template store_grad<NT, true>(gp, trow, i16, rs[g] * (1.f - p.ls_b), col_ok, live ? -p.ls_b * gsc : 0.f);
             else x.template store_grad<NT, false>(gp, trow, i16, rs[g], col_ok, 0.f);
         }
+        lds_order();
+        // the tile is all zeros again: the label slots, not three 16-byte stores per lane (an LDS store costs the wave
+        // issue time by the byte: tools/micro/km_probe.hip)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (own[s]) *gat[s] = 0.f;
         lds_order();
     }
     stamp(p, 7);
