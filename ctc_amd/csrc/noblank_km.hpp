@@ -708,7 +708,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_km_kernel(NoblankParams p
         for (int s = 0; s < 2; ++s) z[s] = pr[s] > 0.f ? __builtin_amdgcn_ldexpf(pr[s], ks[s] - kref) : 0.f;
         float tot = z[0] + z[1];
         row16_allsum(tot);
-        float rinv = (live && tot > 0.f) ? gsc * p.ls_a * __builtin_amdgcn_rcpf(tot) : 0.f;
+        float rinv = (live && tot > 0.f) ? -gsc * p.ls_a * __builtin_amdgcn_rcpf(tot) : 0.f;   // (store_grad adds the tile: MINUS the occupancy)
         if (starved) {
             rinv = __builtin_nanf("");
             raise_status(p.counter, kStatusNoblankStarved);

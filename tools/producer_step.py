@@ -71,3 +71,37 @@ for (T, B, H) in [(150, 10, 33), (150, 64, 33), (150, 256, 33), (150, 10, 38)]:
     err = (one_launch() - torch_loop()).abs().max().item()
     print("T=%d B=%3d H=%d: torch nn.LSTMCell loop %8.1f us | one fused launch per frame %8.1f us | one launch %7.1f us   (max |diff| to torch %.1e)"
           % (T, B, H, timed(torch_loop), timed(step_loop), timed(one_launch), err))
+
+# ---- the head (Linear + BatchNorm1d + ReLU + Dropout, LSTM.py:8-18) for all frames: torch's layers frame by frame (the
+# reference) against ctc_amd_head_forward (one launch), eval mode and train mode (p = 0.3), forward and forward + backward
+for (T, B, K, C) in [(150, 10, 1024, 33), (150, 64, 1024, 33), (150, 256, 1024, 158)]:
+    lin, bn = torch.nn.Linear(K, C).to(dev), torch.nn.BatchNorm1d(C).to(dev)
+    feat = torch.randn(T, B, K, device=dev)
+    mask = torch.nn.functional.dropout(torch.ones(T, B, C, device=dev), 0.3, True)
+    for train in (False, True):
+        bn.train(train)
+
+        def torch_head():
+            with torch.no_grad():
+                return torch.stack([torch.relu(bn(lin(feat[t]))) for t in range(T)]) * mask
+
+        def hip_head():
+            with torch.no_grad():
+                rm, rv = (None, None) if train else (bn.running_mean, bn.running_var)
+                return ctc_amd.head_forward(feat, lin.weight, lin.bias, bn.weight, bn.bias, rm, rv, bn.eps, mask)[0]
+
+        fr = feat.clone().requires_grad_(True)
+
+        def torch_head_train():
+            lin.zero_grad(); bn.zero_grad(); fr.grad = None
+            (torch.stack([torch.relu(bn(lin(fr[t]))) for t in range(T)]) * mask).sum().backward()
+
+        def hip_head_train():
+            lin.zero_grad(); bn.zero_grad(); fr.grad = None
+            rm, rv = (None, None) if train else (bn.running_mean, bn.running_var)
+            producer._HeadFn.apply(fr, lin.weight, lin.bias, bn.weight, bn.bias, rm, rv, bn.eps, mask)[0].sum().backward()
+
+        err = (hip_head() - torch_head()).abs().max().item()
+        print("head T=%d B=%3d K=%d C=%3d %s: torch layers per frame %8.1f us | one launch %7.1f us | fwd+bwd %9.1f / %8.1f us   (max |diff| %.1e)"
+              % (T, B, K, C, "train" if train else "eval ", timed(torch_head, 10), timed(hip_head, 10), timed(torch_head_train, 5),
+                 timed(hip_head_train, 5), err))

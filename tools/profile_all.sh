@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for every bench configuration of one round (run on the GPU box from the repo root):
-#   tools/profile_all.sh r03   ->  gpurun_out/prof_r03_{noblank,noblank2048,binary,blank} + summaries printed
+#   tools/profile_all.sh r03   ->  gpurun_out/prof_${R}_{noblank,noblank2048,binary,blank} + summaries printed
 set -u
 R=${1:-r03}
 O=gpurun_out
