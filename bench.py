@@ -338,6 +338,9 @@ def main():
                 pending[k].wait()
                 pending[k] = None
         torch.cuda.synchronize()
+        if coll and state.get("eager_works"):               # works the watchdog may still hold: it retires finished ones
+            time.sleep(0.6)                                 # every ~100 ms; after that it has no event left to query
+            state["eager_works"] = False
 
     def capture(m, collective=False, gate=False, occupant=0, placement=None):
         """m steps per graph.  collective: one all-reduce of the step's loss per step -- placement "same": a blocking
@@ -391,10 +394,12 @@ def main():
             return None
 
     pending = [None, None]
+    state = {"i": 0, "eager_works": False}
     if coll:                                                # communicator set up outside any capture
         dist.all_reduce(rings[0][:1], op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         rings[0].zero_()
+        state["eager_works"] = True
     graphs = []
     occ_lib = None
     n_occ = a.occupant or 0                                 # (only on request: the default rehearsal runs exactly what N > 1 runs)
@@ -423,7 +428,28 @@ def main():
             capture_note = "graph capture failed: steps issued eagerly"
             launch, M, graphs = "eager", 1, []
             bucket = bucket or 1
-    state = {"i": 0}
+    # Every other graph of this run is captured NOW, before the measurement phase issues its first eager all-reduce:
+    # ProcessGroupNCCL's watchdog thread polls the events of eager works, and an event query from another thread while a
+    # capture is in progress aborts the process on this stack even in the thread-local capture mode (seen once in round 3
+    # and once in round 4, both times in a capture that FOLLOWED eager all-reduces).  Works issued inside a capture are
+    # not handed to the watchdog, so captured collectives are safe; drain() additionally waits out the watchdog's period.
+    gp = gb = None
+    Mb = max(1, min(a.graph_steps, K))
+    want_per_step = coll and not per_step_collective and a.launch == "graph" and a.backend == "nccl" and launch == "graph"
+    want_bucketed = per_step_collective and a.launch == "graph"
+    if want_per_step:
+        gp = try_capture("the per-step all-reduce (secondary figure)", M, collective=True, gate=use_gate, occupant=0)
+    if want_bucketed:
+        gb = try_capture("the bucketed form (secondary figure)", Mb)
+    co_graphs = {}
+    co_specs = (("gated_us_per_step", dict(collective=True, gate=True, occupant=n_occ)),
+                ("ungated_us_per_step", dict(collective=True, gate=False, occupant=n_occ)),
+                ("allreduce_only_us_per_step", dict(collective=True, gate=False, occupant=0, placement="side")),
+                ("allreduce_same_stream_us_per_step", dict(collective=True, gate=False, occupant=0, placement="same")),
+                ("no_collective_us_per_step", dict(collective=False)))
+    if in_graph and n_occ and world == 1:
+        for label, kw in co_specs:
+            co_graphs[label] = try_capture(label, M, **kw)
 
     def run_steps(n, launch=launch, graphs=graphs, M=M, bucket=bucket, graph_collective=in_graph):
         """exactly n steps; N>1: loss contributions all-reduced every `bucket` steps (graph_collective: the graphs
@@ -445,6 +471,7 @@ def main():
                     wl.step(rings[k].data_ptr() + 4 * j, ws, s)
             if coll and not (replayed and graph_collective):
                 pending[k] = dist.all_reduce(rings[k][:max(m, 1)], op=dist.ReduceOp.SUM, async_op=True)
+                state["eager_works"] = True
             state["i"] += 1
             done += m
         for k in (0, 1):
@@ -483,8 +510,7 @@ def main():
     # the primary run has one all-reduce per step), or with one all-reduce per step captured into the graph
     # (`per_step_collective`, when the primary run is the bucketed default)
     per_step = None
-    if coll and not per_step_collective and a.launch == "graph" and a.backend == "nccl" and launch == "graph":
-        gp = try_capture("the per-step all-reduce (secondary figure)", M, collective=True, gate=use_gate, occupant=0)
+    if want_per_step:
         if gp is None:
             per_step = {"error": "capture failed"}
         else:
@@ -495,9 +521,7 @@ def main():
                         "ms_per_step": round(elp / npst * 1e3, 6), "launch": "graph", "graph_steps": M,
                         "loss_allreduce_bucket": 1, "collective_launch": "in the hipGraph, one all-reduce per step (%s stream)" % a.collective_stream}
     bucketed = None
-    if per_step_collective and a.launch == "graph":
-        Mb = max(1, min(a.graph_steps, K))
-        gb = try_capture("the bucketed form (secondary figure)", Mb)
+    if want_bucketed:
         if gb is None:
             bucketed = {"error": "capture failed"}
         else:
@@ -510,15 +534,11 @@ def main():
 
     # rehearsal on one GPU: the same graph with the stand-in collective kernel, gated and not, and without a collective
     coresident = None
-    if in_graph and n_occ and world == 1:
+    if co_graphs:
         coresident = {"occupant": "%d workgroups with rcclGenericKernel's footprint (256 threads, 19744 B LDS, 280 registers "
                                   "per lane), resident %.0f us, where each step's all-reduce kernel would run" % (n_occ, a.occupant_us)}
-        for label, kw in (("gated_us_per_step", dict(collective=True, gate=True, occupant=n_occ)),
-                          ("ungated_us_per_step", dict(collective=True, gate=False, occupant=n_occ)),
-                          ("allreduce_only_us_per_step", dict(collective=True, gate=False, occupant=0, placement="side")),
-                          ("allreduce_same_stream_us_per_step", dict(collective=True, gate=False, occupant=0, placement="same")),
-                          ("no_collective_us_per_step", dict(collective=False))):
-            gx = try_capture(label, M, **kw)
+        for label, _kw in co_specs:
+            gx = co_graphs.get(label)
             if gx is None:
                 coresident[label] = None
                 continue

@@ -373,6 +373,8 @@ extern "C" int ctc_amd_lstm_series_backward(const float *d_series, int64_t ds_st
 // for the backward pass and for the running statistics, which the reference updates frame after frame (a closed form
 // over the T frames, applied by the caller).  Eval mode: the running statistics.  Dropout is a mask tensor the caller
 // hands in (already scaled by 1 / (1 - p)): the random stream stays torch's.
+namespace ctc {
+
 struct HeadParams {
     const float *feat;                                        // [T][B][K]
     int64_t fst, fsb;
@@ -469,6 +471,8 @@ __global__ __launch_bounds__(1024) void head_kernel(HeadParams p)
     }
 }
 
+}  // namespace ctc
+
 extern "C" int ctc_amd_head_forward(const float *feat, int64_t feat_stride_t, int64_t feat_stride_b,
                                     const float *weight, const float *bias, const float *bn_weight, const float *bn_bias,
                                     const float *running_mean, const float *running_var, float eps, const float *mask,
@@ -484,7 +488,7 @@ extern "C" int ctc_amd_head_forward(const float *feat, int64_t feat_stride_t, in
         (reinterpret_cast<uintptr_t>(feat) & 15) != 0 || (reinterpret_cast<uintptr_t>(weight) & 15) != 0)
         return CTC_AMD_ERR_UNSUPPORTED_SHAPE;
     if (running_mean == nullptr && B < 2) return CTC_AMD_ERR_BAD_ARGUMENT;       // (torch raises too: one value per channel)
-    HeadParams p;
+    ctc::HeadParams p;
     p.feat = feat; p.fst = feat_stride_t; p.fsb = feat_stride_b;
     p.w = weight; p.bias = bias; p.gamma = bn_weight; p.beta = bn_bias;
     p.rmean = running_mean; p.rvar = running_var; p.mask = mask; p.eps = eps;
@@ -492,6 +496,6 @@ extern "C" int ctc_amd_head_forward(const float *feat, int64_t feat_stride_t, in
     p.out = out; p.ost = out_stride_t; p.osb = out_stride_b;
     p.lin = linear_out; p.smean = save_mean; p.svar = save_var; p.sinv = save_invstd;
     const int NW = (B + 15) / 16;
-    hipLaunchKernelGGL(head_kernel, dim3(T, (C + 15) / 16), dim3(64 * NW), 0, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(ctc::head_kernel, dim3(T, (C + 15) / 16), dim3(64 * NW), 0, static_cast<hipStream_t>(stream), p);
     return (int)hipGetLastError();
 }
