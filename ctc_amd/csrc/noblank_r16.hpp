@@ -768,6 +768,24 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     const float gsc = p.grad_scale;
     Row::zero_tile(trow, i16);                               // the occupancy tile starts all zero and every group leaves it so
     lds_order();
+    // how far the chains must have come for each group (scalars; made here, in the workers' idle window, so that the
+    // gradient pass behind the chains carries as little scalar bookkeeping as possible -- a wave issues ONE instruction
+    // at a time, scalar or vector)
+    int need_a_[G], need_b_[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        need_a_[g] = 0;
+        need_b_[g] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tk = r16_row(p.T, u, g, k);            // scalar twin of tv[g]
+            if (tk >= 0 && tk < Tlive) {
+                need_a_[g] = max(need_a_[g], tk + 1);
+                need_b_[g] = max(need_b_[g], Tlive - tk);
+            }
+        }
+    }
+    float *const sink = sm.dummy + 4;                        // where the lanes that have nothing to scatter store
     bool starved = false;
 
     // P3: middle-out, one look at the chains' progress per group
@@ -779,15 +797,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 #pragma unroll
     for (int g = G - 1; g >= 0; --g) {
         if (!grp[g]) continue;
-        int need_a = 0, need_b = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int tk = r16_row(p.T, u, g, k);            // scalar twin of tv[g]
-            if (tk >= 0 && tk < Tlive) {
-                need_a = max(need_a, tk + 1);
-                need_b = max(need_b, Tlive - tk);
-            }
-        }
+        const int need_a = need_a_[g], need_b = need_b_[g];
         if (need_a > 0) {
             int spins = 0;
             while (*(lds_cvint *)(sm.cnt + kPipeWorkers) < need_a || *(lds_cvint *)(sm.cnt + kPipeWorkers + 1) < need_b) {
@@ -858,8 +868,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         // MINUS the class occupancy of the four rows, scattered into the all-zero tile
         // (only lanes that own a state write; pass k adds the k-th repetition of a label)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            if (own[s] && occn[s] == 0) *gat[s] = z[s] * rinv;
+        for (int s = 0; s < 2; ++s) *((own[s] && occn[s] == 0) ? gat[s] : sink) = z[s] * rinv;   // (no exec juggling: a select)
         for (int k = 1; k <= max_occ; ++k) {
             lds_order();
 #pragma unroll
@@ -877,8 +886,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         // the tile is all zeros again: the label slots, not three 16-byte stores per lane (an LDS store costs the wave
         // issue time by the byte: tools/micro/km_probe.hip)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            if (own[s]) *gat[s] = 0.f;
+        for (int s = 0; s < 2; ++s) *(own[s] ? gat[s] : sink) = 0.f;
         lds_order();
     }
     stamp(p, 7);
