@@ -785,7 +785,6 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             }
         }
     }
-    float *const sink = sm.dummy + 4;                        // where the lanes that have nothing to scatter store
     bool starved = false;
 
     // P3: middle-out, one look at the chains' progress per group
@@ -868,7 +867,8 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         // MINUS the class occupancy of the four rows, scattered into the all-zero tile
         // (only lanes that own a state write; pass k adds the k-th repetition of a label)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) *((own[s] && occn[s] == 0) ? gat[s] : sink) = z[s] * rinv;   // (no exec juggling: a select)
+        for (int s = 0; s < 2; ++s)
+            if (own[s] && occn[s] == 0) *gat[s] = z[s] * rinv;
         for (int k = 1; k <= max_occ; ++k) {
             lds_order();
 #pragma unroll
@@ -886,7 +886,8 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         // the tile is all zeros again: the label slots, not three 16-byte stores per lane (an LDS store costs the wave
         // issue time by the byte: tools/micro/km_probe.hip)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) *(own[s] ? gat[s] : sink) = 0.f;
+        for (int s = 0; s < 2; ++s)
+            if (own[s]) *gat[s] = 0.f;
         lds_order();
     }
     stamp(p, 7);
