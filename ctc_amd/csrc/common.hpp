@@ -123,6 +123,11 @@ __device__ __forceinline__ void reset_arrivals(unsigned *counter)
 // it).  Zero instructions.
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
+// A value the compiler knows nothing about any more (volatile: never hoisted, merged or duplicated): what is computed
+// from it inside a loop stays inside the loop.
+__device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
+
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2).  Rows of
 // neighbouring samples share 128-byte lines (a row is C*4 bytes, rarely a multiple of 128),
 // so consecutive samples are mapped onto the SAME XCD: the straddling lines are then fetched
@@ -321,6 +326,7 @@ __device__ __forceinline__ int load_label(const void *p, int is64, int64_t i)
 // front of everything that follows, and every later wait on the row loads degrades to vmcnt(0).
 struct ScalarLengths {
     int64_t a, b;
+    __device__ __forceinline__ ScalarLengths() : a(0), b(0) {}
     __device__ __forceinline__ ScalarLengths(const int64_t *pa, const int64_t *pb)
     {
         typedef const __attribute__((address_space(4))) int64_t const_i64;

@@ -46,6 +46,21 @@ struct NoblankParams {
     int koff;                   // noblank_km_kernel: what the exponent recurrence starts with (log2 of the path count / 2)
 };
 
+// Every field through an empty volatile asm: the copy holds the same values, but the compiler no longer knows that
+// they are the launch's constants.  For kernels that LOOP over samples: whatever is computed from `p` inside the loop
+// stays inside (hoisted out, the address arithmetic of a whole sample waits in registers for its turn -- see
+// noblank_r16_kernel<.., PS>).
+__device__ __forceinline__ NoblankParams opaque_params(NoblankParams q)
+{
+#define CTC_OPQ(f) asm volatile("" : "+s"(q.f))
+    CTC_OPQ(x); CTC_OPQ(st); CTC_OPQ(sb); CTC_OPQ(lab); CTC_OPQ(lab64); CTC_OPQ(in_len); CTC_OPQ(tgt_len);
+    CTC_OPQ(T); CTC_OPQ(B); CTC_OPQ(C); CTC_OPQ(S); CTC_OPQ(SP); CTC_OPQ(stop); CTC_OPQ(loss_scale); CTC_OPQ(grad_scale);
+    CTC_OPQ(nll); CTC_OPQ(loss); CTC_OPQ(grad); CTC_OPQ(gamma); CTC_OPQ(lattice); CTC_OPQ(slab); CTC_OPQ(counter);
+    CTC_OPQ(next_round); CTC_OPQ(ls_a); CTC_OPQ(ls_b); CTC_OPQ(koff);
+#undef CTC_OPQ
+    return q;
+}
+
 #ifndef CTC_NOBLANK_THREADS
 #define CTC_NOBLANK_THREADS 1024
 #endif
@@ -509,6 +524,24 @@ static int noblank_run(const float *x, int64_t stride_t, int64_t stride_b,
             }
 #endif
             p.next_round = (B > cus && (size_t)T * ((C * 4 + 127) / 128) <= (size_t)kPipeWorkers * kWave) ? cus : 0;
+            // More than two rounds of samples: one PERSISTENT workgroup per CU that keeps the next sample's rows in a
+            // second set of registers (noblank_r16.hpp), wherever two sets fit the 128 VGPRs of a 16-wave workgroup
+            // (C <= 192) and a gradient is wanted.  T = 150, C = 158, us per launch persistent / one sample per
+            // workgroup: B = 2048 82.7 / 98.0, 1024 41.7 / 45.1, 512 24.3 / 24.1.
+            static const bool no_ps = diag_env("CTC_AMD_NOPS") != 0;
+            if (B > 2 * cus && cus > 0 && !no_ps && p.grad && 4 * n4 + 2 * n2 <= 12) {
+                const dim3 pgrid(cus);
+#define CTC_R16_CASE(K, A, Bq)                                                                          \
+                case K: return nt ? launch<noblank_r16_kernel<A, Bq, true, true>>(pgrid, block, rsmem, s, p)   \
+                                  : launch<noblank_r16_kernel<A, Bq, false, true>>(pgrid, block, rsmem, s, p);
+                switch (4 * n4 + n2) {
+                    CTC_R16_CASE(1, 0, 1) CTC_R16_CASE(2, 0, 2) CTC_R16_CASE(4, 1, 0) CTC_R16_CASE(5, 1, 1)
+                    CTC_R16_CASE(6, 1, 2) CTC_R16_CASE(8, 2, 0) CTC_R16_CASE(9, 2, 1) CTC_R16_CASE(10, 2, 2)
+                    CTC_R16_CASE(12, 3, 0)
+                    default: break;
+                }
+#undef CTC_R16_CASE
+            }
 #define CTC_R16_CASE(K, A, Bq)                                                                          \
             case K: return nt ? launch<noblank_r16_kernel<A, Bq, true>>(grid, block, rsmem, s, p)         \
                               : launch<noblank_r16_kernel<A, Bq, false>>(grid, block, rsmem, s, p);

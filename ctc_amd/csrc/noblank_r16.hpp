@@ -130,11 +130,10 @@ static size_t r16_smem_bytes(int T, int SP, int C)
 // times per chain; a block of steps whose requirement is already met costs no look at all.
 // Returns alpha[T_b-1, L_b-1] (FWD) as a cell.
 template <bool FWD>
-__device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Smem &sm, int T, int Tb, int L, int SP)
+__device__ __forceinline__ cell_t r16_chain(const NoblankParams &p, const R16Smem &sm, int T, int Tb, int L, int SP, const int lane)
 {
     constexpr int G = kPipeRows / 4;
     constexpr int D = FWD ? 1 : -1;
-    const int lane = lane_id();
     // Lanes beyond the states stay ALIVE on the spare state row (zero emissions: no mass ever, and
     // nothing a real state reads): the same instruction stream runs faster with the whole wave
     // switched on than with 20 lanes (tools/micro/chain_asm.hip).  A backward lane reads its upper
@@ -470,6 +469,14 @@ struct R16Row {
             if (k < N2 - 1 || col_ok) grad_store<NT>(reinterpret_cast<f2_t *>(g + off2(k, i16)), v);
         }
     }
+    // a "use" of every register of the row: where the compiler waits for the row's loads
+    __device__ __forceinline__ void touch() const
+    {
+#pragma unroll
+        for (int j = 0; j < N4; ++j) asm volatile("" ::"v"(a[j]));
+#pragma unroll
+        for (int k = 0; k < N2; ++k) asm volatile("" ::"v"(c[k]));
+    }
     template <bool NT>
     __device__ static __forceinline__ void store_zero(float *g, int i16, bool col_ok)
     {
@@ -496,7 +503,14 @@ static bool r16_shape(int C, int &n4, int &n2)
     return true;
 }
 
-template <int N4, int N2, bool NT>
+// PS ("persistent", more samples than CUs): ONE workgroup per CU for the whole launch, taking the samples the
+// one-sample-per-workgroup launch would have dispatched to it one after the other (virtual block vb = blockIdx +
+// r * gridDim).  What it saves per sample is everything a fresh workgroup waits for before its chains can start:
+// the dispatch, and above all the rows -- a worker holds the NEXT sample's rows in a second set of registers, loaded
+// while this sample's chains run (instead of the 4-byte-per-line L2 prefetch of the one-sample form), so the next
+// sample starts with its rows, lengths and labels already there.  Two workgroup barriers per sample (everyone is done
+// with the lattice / the lattice is initialised); N4 / N2 whose two row sets do not fit 128 VGPRs keep the other form.
+template <int N4, int N2, bool NT, bool PS = false>
 __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams p)
 {
     extern __shared__ float4 smem_raw[];
@@ -504,11 +518,12 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     constexpr int RP = Row::kCols;                           // floats per staged row
     constexpr int G = kPipeRows / 4;                         // groups of four rows per worker
     const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, RP);
-    const int b = xcd_sample(blockIdx.x, p.B), tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    int vb = blockIdx.x;                                     // (PS: advances by gridDim.x per sample)
+    int b = xcd_sample(vb, p.B);
     if (tid == 64 * kChainB) note_arrival(p.counter, b);        // (the beta chain wave has no other vector-memory operation)
     const int u = (w == 0 || w == kChainB) ? -1 : (w < kChainB ? w - 1 : w - 2);
     const int rho = lane >> 4, i16 = lane & 15;              // row of the group, position inside the row
-    const float ninf = -__builtin_inff();
 
     if (CTC_DIAG(p) == 1) return;                                 // diagnostic: cost of the bare dispatch
     stamp(p, 0);
@@ -526,73 +541,125 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     // The two lengths come through the SCALAR memory path (uniform address): a vector load here is
     // followed by a readfirstlane, i.e. a full memory round trip BEFORE the first row load is issued,
     // and later waits on the row loads degrade to vmcnt(0).
-    const ScalarLengths len(p.in_len + b, p.tgt_len + b);
-    // this lane's row in each group
-    int tv[G];
+    ScalarLengths len(p.in_len + b, p.tgt_len + b);
+    // this lane's row in each group (the same rows t for every sample: they depend on T alone)
+    int tv0[G];
     Row v[G];
+    // PS: groups [0, NX) of the NEXT sample wait in a second set of registers (loaded while this sample's chains run:
+    // group 0 is what the next sample's chains wait for), the other groups are loaded in place as soon as the
+    // gradient pass is through with this sample's (P3 takes the groups last to first).
+    // Measured, T = 150, C = 158, us per launch with NX = 1 / 2 / 3 (the one-sample form: 98.0 / 45.1 / 24.1):
+    // B = 2048 (non-temporal stores) 82.9 / 82.7 / 90.1, B = 1024 (write-through stores) 47.0 / 42.8 / 41.7,
+    // B = 512 26.4 / 24.9 / 24.3 -- NX = 0 (every group loaded in place: group 0's load queues behind the sample's last
+    // gradient stores) 88.7 / 50.3 / 27.5.
+#ifdef CTC_R16_NX
+    constexpr int NX = PS ? CTC_R16_NX : 0;
+#else
+    constexpr int NX = PS ? (NT ? 2 : 3) : 0;
+#endif
+    Row nx[NX > 0 ? NX : 1];
     const bool col_ok = Row::off_last(i16) < p.C;            // last chunk inside the row
     const int c_last = col_ok ? Row::off_last(i16) : p.C - (Row::kLast4 ? 4 : 2);
+    // Groups whose four slots all lie beyond the sequence (the last group of the last workers: 14 x 12 slots
+    // for T rows) are skipped -- a group costs its instructions whatever its rows hold.  Wave-uniform.
+    const int Hh = (p.T + 1) >> 1;
+    bool grp[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) grp[g] = u >= 0 && 2 * kPipeWorkers * g + 2 * u < Hh;
+    int klab = 0;                                            // PS, wave 0: the sample's raw labels (one per lane)
+    if (PS && w == 0 && lane < p.S) klab = load_label(p.lab, p.lab64, (int64_t)b * p.S + lane);
     if (u >= 0) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            tv[g] = r16_row(p.T, u, g, rho);
-            v[g].load(row_ptr(p, tv[g] >= 0 ? tv[g] : 0, b), i16, c_last);
+            tv0[g] = r16_row(p.T, u, g, rho);
+            if (g >= NX) v[g].load(row_ptr(p, tv0[g] >= 0 ? tv0[g] : 0, b), i16, c_last);
+            else nx[g].load(row_ptr(p, tv0[g] >= 0 ? tv0[g] : 0, b), i16, c_last);
+        }
+        stamp_setup(p, 1);                                   // loads issued
+        if (PS) {
+            // PS: every wait for a row load of the FIRST sample is taken here, once per launch (and in the same branch
+            // as the loads: the compiler places its waits by paths, not by conditions).  Inside the loop a wait on a
+            // load can only say "at most n operations outstanding", and a load that could still be in flight at the
+            // loop's head would make the first groups' waits count the previous sample's gradient stores.
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g < NX) nx[g].touch();
+                else v[g].touch();
+            }
         }
     }
-    stamp_setup(p, 1);                                       // loads issued
-    int64_t Tb64, L64;
-    len.get(Tb64, L64);
-    stamp_setup(p, 2);                                       // lengths there
-    const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
-    const int Tb = ok ? (int)Tb64 : 0, L = ok ? (int)L64 : 0;
-    // The labels are wave 0's business alone (S <= 31 < 64), in a branch of its own: a vector load on
-    // the workers' (static) path would make every later wait on their row loads a vmcnt(0).
-    if (w == 0) {
-        int k = 0;
-        if (lane < L) {
-            k = load_label(p.lab, p.lab64, (int64_t)b * p.S + lane) % p.C;
-            if (k < 0) k += p.C;                             // python negative index (NoBlankCTC.py:102)
-        }
-        if (lane < p.SP) sm.lab[lane] = k;
-    }
-    stamp_setup(p, 3);                                       // (wave 0: labels stored)
-    // (LDS initialisation that needs no loaded value: it overlaps the loads' latency)
+    const float ninf = -__builtin_inff();
+    typedef const volatile __attribute__((address_space(3))) int lds_cvint;
+    // Per-sample state of the loops below (PS: one pass per sample of this workgroup; otherwise one pass).  The two
+    // ROLES run loops of their own -- a wave never changes its role, and in one common loop everything a worker carries
+    // from sample to sample (the next sample's rows ...) would stay allocated through the chains' code and vice versa.
+    int Tb = 0, L = 0, bn = b, vbn = vb, klab_n = 0;
+    bool more = false;                                       // (uniform over the workgroup)
+    ScalarLengths len_n;
     const cell_t zero = make_cell(0.f, 0);
-    for (int i = tid; i < (p.SP + 1) * sm.TP; i += kThreads) sm.em[i - kR16Pad] = zero;   // pads + spare row
-    if (tid < 16) sm.cnt[tid] = 0;
-    if (tid == 16) *sm.done = 0;
-    if (tid == 17) sm.occ[((p.SP + 3) & ~3) + 1] = 0;
-    if (tid < 8) sm.dummy[tid] = 0.f;
-    // LDS-only barrier: __syncthreads() would also wait for every row load of the wave (s_waitcnt
-    // vmcnt(0)), but a worker only needs its first group's rows to start
-    stamp_setup(p, 4);                                       // LDS initialised, at the barrier
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    stamp(p, 1);
-    stamp_setup(p, 5);
-    if (CTC_DIAG(p) == 2) return;                                 // diagnostic: dispatch + setup (+ loads in flight)
-
-    if (Tb == 0) {                                           // no alignment exists: nll = 1e13, zero gradient
+    // start of a sample: lengths, labels, the lattice's pads, the counters; ends in the workgroup's barrier
+    auto begin = [&](const bool chain_role) -> bool {
+        int64_t Tb64, L64;
+        len.get(Tb64, L64);
+        stamp_setup(p, 2);                                   // lengths there
+        const bool ok = L64 >= 1 && L64 <= p.S && Tb64 >= L64 && Tb64 <= p.T;
+        Tb = ok ? (int)Tb64 : 0;
+        L = ok ? (int)L64 : 0;
+        vbn = vb + (int)gridDim.x;
+        more = PS && vbn < p.B;
+        bn = more ? xcd_sample(vbn, p.B) : b;
+        // PS: the next sample's lengths and labels travel while this one runs
+        if (PS) len_n = ScalarLengths(p.in_len + bn, p.tgt_len + bn);
+        klab_n = 0;
+        // The labels are wave 0's business alone (S <= 31 < 64), in a branch of its own: a vector load on
+        // the workers' (static) path would make every later wait on their row loads a vmcnt(0).
+        if (chain_role && w == 0) {
+            int k = 0;
+            if (lane < L) {
+                k = (PS ? klab : load_label(p.lab, p.lab64, (int64_t)b * p.S + lane)) % p.C;
+                if (k < 0) k += p.C;                         // python negative index (NoBlankCTC.py:102)
+            }
+            if (lane < p.SP) sm.lab[lane] = k;
+            if (more && lane < p.S) klab_n = load_label(p.lab, p.lab64, (int64_t)bn * p.S + lane);
+        }
+        stamp_setup(p, 3);                                   // (wave 0: labels stored)
+        // (LDS initialisation that needs no loaded value: it overlaps the loads' latency)
+        for (int i = tid; i < (p.SP + 1) * sm.TP; i += kThreads) sm.em[i - kR16Pad] = zero;   // pads + spare row
+        if (tid < 16) sm.cnt[tid] = 0;
+        if (tid == 16) *sm.done = 0;
+        if (tid == 17) sm.occ[((p.SP + 3) & ~3) + 1] = 0;
+        if (tid < 8) sm.dummy[tid] = 0.f;
+        // LDS-only barrier: __syncthreads() would also wait for every row load of the wave (s_waitcnt
+        // vmcnt(0)), but a worker only needs its first group's rows to start
+        stamp_setup(p, 4);                                   // LDS initialised, at the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stamp(p, 1);
+        stamp_setup(p, 5);
+        return CTC_DIAG(p) != 2;                                  // diagnostic: dispatch + setup (+ loads in flight)
+    };
+    // end of a sample: false when it was the workgroup's last; otherwise on to the next one, behind a barrier
+    // (every wave is done with this sample's lattice and tiles)
+    auto advance = [&]() -> bool {
+        if (!more) return false;
+        vb = vbn;
+        b = bn;
+        len = len_n;
+        klab = klab_n;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        return true;
+    };
+    // ---------------------------------------------------------------- chain waves
+    auto chain_sample = [&](const NoblankParams &p, const int lane) {
+    const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, RP);
+    if (Tb == 0) {                                           // no alignment exists: nll = 1e13 (the workers: zero gradient)
         if (w == 0)
             publish_and_reduce_sum(-kNeg, b, p.B, p.nll, p.loss, p.loss_scale, p.counter);
-        if (u >= 0 && p.grad) {
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-                if (tv[g] >= 0) Row::template store_zero<NT>(p.grad + ((int64_t)tv[g] * p.B + b) * p.C, i16, col_ok);
-        }
-        if (u >= 0 && p.gamma) {                              // posteriors of a sample without alignment: zeros
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-                for (int l = i16; l < p.S && tv[g] >= 0; l += 16) p.gamma[((int64_t)b * p.T + tv[g]) * p.S + l] = 0.f;
-        }
         return;
     }
-    typedef const volatile __attribute__((address_space(3))) int lds_cvint;
-
-    // ---------------------------------------------------------------- chain waves
-    if (u < 0) {
+    {
         __builtin_amdgcn_s_setprio(3);                       // the chains are the critical path
         if (w == 0) {
-            const cell_t a = r16_chain<true>(p, sm, p.T, Tb, L, p.SP);
+            const cell_t a = r16_chain<true>(p, sm, p.T, Tb, L, p.SP, lane);
             stamp(p, 11);
             // nll = -log alpha[T_b-1, L_b-1] (NoBlankCTC.py:58-68,139).  The chains ran on emissions that lack a
             // per-row constant (the row's log-sum-exp and, smoothed, the b sum_n lp[n] term: the posteriors are
@@ -626,13 +693,56 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
                 }
             }
         } else if (p.grad || p.gamma) {
-            r16_chain<false>(p, sm, p.T, Tb, L, p.SP);
+            r16_chain<false>(p, sm, p.T, Tb, L, p.SP, lane);
             stamp(p, 11);
+        }
+    }
+    };                                                       // (chain_sample)
+
+    // ---------------------------------------------------------------- workers
+    // (`lane`, `u`: opaque copies of the outer values, new ones per sample.  Nearly everything a worker computes --
+    // tile and cell addresses, row pointers, masks -- derives from the lane, the worker index and launch constants;
+    // in the PS loop the compiler would hoist ALL of it out of the loop and keep it in registers: 128 VGPRs and
+    // a hundred spilled SGPRs for rows of two registers.)
+    auto worker_sample = [&](const NoblankParams &p, const int lane, const int u) {
+    const R16Smem sm(reinterpret_cast<float *>(smem_raw), p.T, p.SP, RP);
+    const int rho = lane >> 4, i16 = lane & 15;
+    int tv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) tv[g] = PS ? opaque_v(tv0[g]) : tv0[g];
+    // PS launches always want the gradient and never the posteriors (the host takes the one-sample form for those), and
+    // a sample without alignment goes through the ordinary path as a sample without live rows (T_b = L_b = 0: nothing
+    // is published, every scale is 0, the gradient rows come out as zeros): ONE path through the loop.  The compiler
+    // places its waits for the next sample's row loads by control-flow paths; with a side path that loads and leaves,
+    // the main path waited for its own last gradient stores at the end of every sample.
+    const bool has_grad = PS || p.grad != nullptr, has_gamma = !PS && p.gamma != nullptr;
+    // PS: the next sample's rows into the spare register set (all of this sample's rows are in `v` by then)
+    // (unconditional, like every load of a next sample's rows: behind the workgroup's last sample they fetch that
+    // sample's rows once more, and nobody waits for them -- a load under a condition leaves the compiler with two
+    // candidates for the registers at the loop's head, and it keeps both: 30 registers and as many copies)
+    auto load_next = [&]() {
+        if (!PS) return;
+#pragma unroll
+        for (int g = 0; g < NX; ++g) nx[g].load(row_ptr(p, tv[g] >= 0 ? tv[g] : 0, bn), i16, c_last);
+    };
+    // ... and of the groups that are loaded in place, once this sample no longer needs the registers
+#define CTC_R16_RELOAD(g)                                                                             \
+    do {                                                                                              \
+        if (PS && (g) >= NX) v[g].load(row_ptr(p, tv[g] >= 0 ? tv[g] : 0, bn), i16, c_last); \
+    } while (0)
+    if (!PS && Tb == 0) {                                    // no alignment exists: zero gradient
+        if (p.grad) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (tv[g] >= 0) Row::template store_zero<NT>(p.grad + ((int64_t)tv[g] * p.B + b) * p.C, i16, col_ok);
+        }
+        if (p.gamma) {                                       // posteriors of a sample without alignment: zeros
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                for (int l = i16; l < p.S && tv[g] >= 0; l += 16) p.gamma[((int64_t)b * p.T + tv[g]) * p.S + l] = 0.f;
         }
         return;
     }
-
-    // ---------------------------------------------------------------- workers
     float *tile = sm.stage + (size_t)u * 4 * RP;             // this worker's staging / occupancy tile
     float *trow = tile + rho * RP;                           // this lane's row of it
     // states served by this lane in the two passes: l = i16 and l = 16 + i16 (S <= 31)
@@ -646,12 +756,6 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     const bool own[2] = {lst[0] < L, lst[1] < L};
     const bool smooth = p.ls_b != 0.f;                       // (wave-uniform)
     cell_t *const spare_w = reinterpret_cast<cell_t *>(sm.dummy);
-    // Groups whose four slots all lie beyond the sequence (the last group of the last workers: 14 x 12 slots
-    // for T rows) are skipped -- a group costs its instructions whatever its rows hold.  Wave-uniform.
-    const int Hh = (p.T + 1) >> 1;
-    bool grp[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) grp[g] = 2 * kPipeWorkers * g + 2 * u < Hh;
     float mrow[G];                                           // row maximum
     // P1a -- what the CHAINS wait for, for all groups first: the labels' logits relative to the row maximum,
     // e = (x[lab_l] - max) log2e (times a when smoothed), split into 2^floor * 2^frac cells.  The row's
@@ -663,6 +767,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         // published its first group: the waves that are behind go first.
         if (g == 0) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(1);
+        if (g < NX) v[g] = nx[g];
         if (grp[g]) {
             Row &x = v[g];
             const int t = tv[g];
@@ -698,6 +803,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         if (CTC_DIAG(p) < 0) stamp(p, 8 + g);                     // diagnostic: group g published
     }
     __builtin_amdgcn_s_setprio(0);
+    load_next();
     // P1b -- beside the running chains: the row registers become exp(x - max) (P3 needs softmax(x) = that times
     // 1/sum), the per-row constant of the loss is  -a log2 sum + b sum_n lp[n]  in log2 units
     // (sum_n lp[n] = (sum_n x_n - C max) log2e - C log2 sum, NoBlankCTC.py:100-107; plain loss: a = 1, b = 0).
@@ -732,7 +838,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     // Occurrence index of every state among equal labels (0 = first): repeated labels add up in the workers' occupancy
     // tiles, one plain read-modify-write pass per repetition (P3).  The last worker makes the table here, while the
     // chains run -- it used to sit in front of the alpha chain, which therefore started (and ended) 0.3 us behind beta.
-    if (u == kPipeWorkers - 1 && p.grad) {
+    if (u == kPipeWorkers - 1 && has_grad) {
         const int kl = lane < p.SP ? sm.lab[lane] : -1;
         int oc = 0;
         for (int l2 = 0; l2 < L; ++l2) {
@@ -752,7 +858,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     // One 4-byte load per lane, one 128-byte line each, pulls that sample into this XCD's L2 while the chains
     // of this one run: 14 workers x 64 lanes cover its T rows of C floats.  The value is never used.
     float prefetched = 0.f;
-    if (p.next_round > 0 && (int)blockIdx.x + p.next_round < p.B) {
+    if (!PS && p.next_round > 0 && (int)blockIdx.x + p.next_round < p.B) {
         const int nb = xcd_sample(blockIdx.x + p.next_round, p.B);
         const int line = u * kWave + lane;                   // 0 .. 895
         const int lines_per_row = (p.C * 4 + 127) / 128;
@@ -762,12 +868,18 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         typedef const float __attribute__((address_space(1))) gfloat;
         if (t < p.T) prefetched = *(gfloat *)(row_ptr(p, t, nb) + (c < p.C ? c : p.C - 1));
     }
-    if (!p.grad && !p.gamma) return;
+    if (!has_grad && !has_gamma) return;
 
     const int Tlive = Tb;
     const float gsc = p.grad_scale;
     Row::zero_tile(trow, i16);                               // the occupancy tile starts all zero and every group leaves it so
     lds_order();
+    if (PS) {
+        // the next sample's rows are waited for HERE, in the workers' idle window and with no gradient store in flight
+        // (see the launch's first wait above)
+#pragma unroll
+        for (int g = 0; g < NX; ++g) nx[g].touch();
+    }
     // how far the chains must have come for each group (scalars; made here, in the workers' idle window, so that the
     // gradient pass behind the chains carries as little scalar bookkeeping as possible -- a wave issues ONE instruction
     // at a time, scalar or vector)
@@ -811,7 +923,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         if (CTC_DIAG(p) < 0) stamp(p, 3 + (G - 1 - g));
         if (g == G - 1) asm volatile("" ::"v"(prefetched));    // the prefetched value is "used" here (and dropped)
         int occn[2] = {0, 0}, max_occ = 0;
-        if (need_a > 0 && !occ_seen && p.grad) {             // (once per wave; the table was made long before the chains cross)
+        if (need_a > 0 && !occ_seen && has_grad) {             // (once per wave; the table was made long before the chains cross)
             int spins = 0;
             while (*(lds_cvint *)(sm.occ + ((p.SP + 3) & ~3) + 1) == 0) {
                 if (++spins >= kSpinLimit) { starved = true; break; }
@@ -820,7 +932,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             lds_order();
             occ_seen = true;
         }
-        if (need_a > 0 && p.grad) {                          // (wave-uniform; a group without live rows adds nothing)
+        if (need_a > 0 && has_grad) {                          // (wave-uniform; a group without live rows adds nothing)
             occn[0] = own[0] ? sm.occ[lst[0]] : 0;
             occn[1] = own[1] ? sm.occ[lst[1]] : 0;
             max_occ = __builtin_amdgcn_readfirstlane(sm.occ[(p.SP + 3) & ~3]);
@@ -851,7 +963,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         for (int s = 0; s < 2; ++s) z[s] = __builtin_amdgcn_ldexpf(pr[s], ks[s] - kref);
         float tot = z[0] + z[1];
         row16_allsum(tot);
-        if (p.gamma) {                                       // (wave-uniform) ctc_amd_noblank_posteriors: gamma[b][t][l] instead of a gradient
+        if (has_gamma) {                                     // (wave-uniform) ctc_amd_noblank_posteriors: gamma[b][t][l] instead of a gradient
             const float ginv = (live && tot > 0.f) ? __builtin_amdgcn_rcpf(tot) : 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -889,9 +1001,26 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         for (int s = 0; s < 2; ++s)
             if (own[s]) *gat[s] = 0.f;
         lds_order();
+        CTC_R16_RELOAD(g);
     }
     stamp(p, 7);
     spread(1);
+#undef CTC_R16_RELOAD
+    };                                                       // (worker_sample)
+
+    if (u < 0) {
+        for (;;) {
+            if (!begin(true)) return;
+            chain_sample(p, PS ? opaque_v(lane) : lane);
+            if (!advance()) return;
+        }
+    }
+    for (;;) {
+        if (!begin(false)) return;
+        if (PS) worker_sample(p, opaque_v(lane), opaque_s(u));
+        else worker_sample(p, lane, u);
+        if (!advance()) return;
+    }
 }
 
 // ---- diagnostic probe (tools/chain_probe.py): the chains alone, every row already published ------
@@ -951,7 +1080,7 @@ __global__ __launch_bounds__(kThreads, 4) void r16_chain_probe_kernel(NoblankPar
         return;
     }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const cell_t c = w == 0 ? r16_chain<true>(p, sm, p.T, p.T, p.SP, p.SP) : r16_chain<false>(p, sm, p.T, p.T, p.SP, p.SP);
+    const cell_t c = w == 0 ? r16_chain<true>(p, sm, p.T, p.T, p.SP, p.SP, lane) : r16_chain<false>(p, sm, p.T, p.T, p.SP, p.SP, lane);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (lane == 0 && blockIdx.x == 0) {
         out[w == 0 ? 0 : 1] = t1 - t0;

@@ -770,6 +770,45 @@ def test_config4_single_gpu_shape_full_size(dev, variant):
     assert np.abs(r["grad"].sum(axis=2)).max() < 1e-7 if variant == "noblank" else True
 
 
+@pytest.mark.parametrize("shape,lam", [((150, 700, 158, 20), None), ((60, 530, 64, 31), None), ((37, 600, 34, 9), None),
+                                       ((90, 1030, 192, 12), 0.9), ((168, 515, 20, 5), None), ((150, 2100, 158, 20), None)])
+def test_noblank_more_samples_than_cus_persistent(dev, shape, lam):
+    """B > 2 #CUs: the persistent form of the four-rows-per-wave kernel (one workgroup per CU walks its samples, the next
+    sample's rows waiting in registers).  Ragged T_b / L_b, samples without alignment in between, B no multiple of the
+    grid, with and without a gradient, smoothed emission; bit-identical to the same samples run 200 at a time (the
+    one-sample-per-workgroup form, B <= #CUs) and against the float64 oracle."""
+    import ctc_amd
+    T, B, C, S = shape
+    x, lab, Tb, L = synth_noblank(sum(shape), T, B, C, S, var_T=True)
+    bad = list(range(5, B, 97))                              # no alignment: L_b > T_b
+    for b in bad:
+        L[b] = min(S, T)
+        Tb[b] = max(1, int(L[b]) - 1)
+        lab[b, :int(L[b])] = torch.arange(int(L[b]), dtype=lab.dtype) % C
+    kw = {} if lam is None else {"label_smoothing": lam}
+    r = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev, **kw)
+    ok = np.array([b for b in range(B) if b not in bad])
+    assert (r["nll"][bad] >= 1e12).all() and np.abs(r["grad"][:, bad]).max() == 0.0
+    ref = ctc_numpy.noblank_ctc(np_(x)[:, ok], np_(lab)[ok], np_(Tb)[ok], np_(L)[ok], np.float64, **kw)
+    assert (np.abs(r["nll"][ok] - ref["nll"]) <= NLL_RTOL * np.maximum(1.0, np.abs(ref["nll"]))).all()
+    assert np.abs(r["grad"][:, ok] * (B / len(ok)) - ref["grad"]).max() < 2e-6 * max(1.0, 64.0 / B) * 4
+    # chunks of <= 200 samples take the one-sample-per-workgroup form: same numbers, bit for bit (gradient scaled by the
+    # chunk's own 1/B: compare through the per-sample nll and the unscaled rows)
+    for lo in range(0, B, 200):
+        hi = min(B, lo + 200)
+        rc = run_hip(ctc_amd.noblank_ctc_loss, x[:, lo:hi], lab[lo:hi], Tb[lo:hi], L[lo:hi], dev, **kw)
+        assert (rc["nll"] == r["nll"][lo:hi]).all()
+        assert np.abs(rc["grad"] * ((hi - lo) / B) - r["grad"][:, lo:hi]).max() <= 1e-9
+    # forward only
+    with torch.no_grad():
+        loss, nll = ctc_amd.noblank_ctc_loss(x.to(dev), lab.to(dev), Tb.to(dev), L.to(dev), **kw)
+    torch.cuda.synchronize()
+    assert (np_(nll) == r["nll"]).all()
+    # twice the same
+    r2 = run_hip(ctc_amd.noblank_ctc_loss, x, lab, Tb, L, dev, **kw)
+    assert (r2["grad"] == r["grad"]).all() and r2["loss"] == r["loss"]
+
+
 def test_sharded_loss_hip_path_single_rank(dev):
     """ShardedCTCLoss with the real (HIP) local compute, 1-rank degenerate mode: a shard of a
     larger global batch reproduces its slice of the full-batch loss and gradient."""

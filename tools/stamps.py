@@ -26,7 +26,8 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402
 
-wl = bench.Workload(sys.argv[1] if len(sys.argv) > 1 else "noblank", 256, 256, torch.device("cuda:0"), 0)
+_B = int(sys.argv[2]) if len(sys.argv) > 2 else 256          # (more than #CUs: the persistent form -- the LAST sample's stamps remain)
+wl = bench.Workload(sys.argv[1] if len(sys.argv) > 1 else "noblank", _B, _B, torch.device("cuda:0"), 0)
 ws = wl.new_workspace()
 loss = torch.zeros(4, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
