@@ -367,9 +367,22 @@ __device__ __forceinline__ void stamp(const P &p, int slot)
 template <typename P>
 __device__ __forceinline__ void stamp_setup(const P &p, int slot)
 {
-    if (CTC_DIAG(p) > -100) return;
+    if (CTC_DIAG(p) > -100 || CTC_DIAG(p) <= -200) return;
     if (blockIdx.x == 0 && wave_id() == -CTC_DIAG(p) - 100 && lane_id() == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * slot;
+        o[0] = __builtin_amdgcn_s_memtime();
+        o[1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// Third diagnostic mode (CTC_AMD_DEBUG_STOP = base - wave, base = -200, -300, ...): kernels that loop over samples
+// stamp one slot per SAMPLE (slot = sample index % 12) at one point of the loop; same slots, same reader.
+template <typename P>
+__device__ __forceinline__ void stamp_mode(const P &p, int base, int slot)
+{
+    if (CTC_DIAG(p) > base || CTC_DIAG(p) <= base - 64) return;
+    if (blockIdx.x == 0 && wave_id() == base - CTC_DIAG(p) && lane_id() == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.counter) + 8 + 2 * (slot % 12);
         o[0] = __builtin_amdgcn_s_memtime();
         o[1] = __builtin_amdgcn_s_memrealtime();
     }

@@ -635,11 +635,15 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         stamp(p, 1);
         stamp_setup(p, 5);
+        stamp_mode(p, -200, (vb - (int)blockIdx.x) / (int)gridDim.x);   // (per sample: the lattice is initialised)
+        if ((vb - (int)blockIdx.x) / (int)gridDim.x < 6) stamp_mode(p, -400, (vb - (int)blockIdx.x) / (int)gridDim.x);   // (-400: starts in slots 0..5, ends in 6..11)
         return CTC_DIAG(p) != 2;                                  // diagnostic: dispatch + setup (+ loads in flight)
     };
     // end of a sample: false when it was the workgroup's last; otherwise on to the next one, behind a barrier
     // (every wave is done with this sample's lattice and tiles)
     auto advance = [&]() -> bool {
+        stamp_mode(p, -300, (vb - (int)blockIdx.x) / (int)gridDim.x);   // (per sample: this wave is done with it)
+        if ((vb - (int)blockIdx.x) / (int)gridDim.x < 6) stamp_mode(p, -400, 6 + (vb - (int)blockIdx.x) / (int)gridDim.x);
         if (!more) return false;
         vb = vbn;
         b = bn;
