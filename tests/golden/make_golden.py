@@ -134,16 +134,16 @@ def F2(NB, NBB):
 
 
 def F3(NB, NBB):
-    """Charades-shaped reduced batch: T=150 C=158 S=20 (B=4 each; ~10 s each)."""
-    x, lab, Tb, L = synth_noblank(2, 150, 4, 158, 20, var_T=True)
+    """Charades-shaped reduced batch: B=8 T=150 C=158 S=20 for both variants (~20-40 s each)."""
+    x, lab, Tb, L = synth_noblank(2, 150, 8, 158, 20, var_T=True)
     t0 = time.time()
     loss, nll, grad = run_noblank(NB, x, lab, Tb, L)
-    print("  noblank T=150 B=4: %.1f s" % (time.time() - t0))
+    print("  noblank T=150 B=8: %.1f s" % (time.time() - t0))
     save("charades_noblank", x=x, lab=lab, in_len=Tb, tgt_len=L, loss=loss, nll=nll, grad=grad)
-    xb, y, Tb2, L2 = synth_binary(3, 150, 3, 158, 20, var_T=True)
+    xb, y, Tb2, L2 = synth_binary(3, 150, 8, 158, 20, var_T=True)
     t0 = time.time()
     loss, nll, grad = run_noblank(NBB, xb, y, Tb2, L2)
-    print("  binary T=150 B=3: %.1f s" % (time.time() - t0))
+    print("  binary T=150 B=8: %.1f s" % (time.time() - t0))
     save("charades_binary", x=xb, y=y, in_len=Tb2, tgt_len=L2, loss=loss, nll=nll, grad=grad)
 
 
