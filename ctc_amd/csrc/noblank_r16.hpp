@@ -901,6 +901,18 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
             }
         }
     }
+    // ... and the addresses the gradient pass needs -- the lattice row of the lane's two states, the gradient row of every
+    // group: 32-bit multiplies (quarter rate) and 64-bit address arithmetic that the compiler otherwise redoes per group,
+    // behind the chains (made opaque: a value it cannot see through stays in its register)
+    int crow[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) crow[s] = opaque_v((lst[s] < p.SP ? lst[s] : p.SP) * sm.TP);
+    float *grow[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        grow[g] = p.grad + ((int64_t)(tv[g] > 0 ? tv[g] : 0) * p.B + b) * p.C;
+        asm volatile("" : "+v"(grow[g]));
+    }
     bool starved = false;
 
     // P3: middle-out, one look at the chains' progress per group
@@ -908,7 +920,22 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
     // that brings a row's terms into range need not be the row's own maximum: a lane keeps the one of the first
     // live row it meets (`kref`) and the later groups skip that reduction.
     int kref = 0;
-    bool have_ref = false, occ_seen = false;
+    bool have_ref = false;
+    // the lane's two states in the occurrence table (made by the last worker right behind its P1b, long before the chains
+    // cross): read once per sample, here, not once per group behind the chains
+    int occn[2] = {0, 0}, max_occ = 0;
+    if (has_grad) {
+        int spins = 0;
+        while (*(lds_cvint *)(sm.occ + ((p.SP + 3) & ~3) + 1) == 0) {
+            if (++spins >= kSpinLimit) { starved = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        lds_order();
+        occn[0] = own[0] ? sm.occ[lst[0]] : 0;
+        occn[1] = own[1] ? sm.occ[lst[1]] : 0;
+        max_occ = __builtin_amdgcn_readfirstlane(sm.occ[(p.SP + 3) & ~3]);
+    }
+    const bool first_occ[2] = {own[0] && occn[0] == 0, own[1] && occn[1] == 0};
 #pragma unroll
     for (int g = G - 1; g >= 0; --g) {
         if (!grp[g]) continue;
@@ -926,21 +953,6 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 #endif
         if (CTC_DIAG(p) < 0) stamp(p, 3 + (G - 1 - g));
         if (g == G - 1) asm volatile("" ::"v"(prefetched));    // the prefetched value is "used" here (and dropped)
-        int occn[2] = {0, 0}, max_occ = 0;
-        if (need_a > 0 && !occ_seen && has_grad) {             // (once per wave; the table was made long before the chains cross)
-            int spins = 0;
-            while (*(lds_cvint *)(sm.occ + ((p.SP + 3) & ~3) + 1) == 0) {
-                if (++spins >= kSpinLimit) { starved = true; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            lds_order();
-            occ_seen = true;
-        }
-        if (need_a > 0 && has_grad) {                          // (wave-uniform; a group without live rows adds nothing)
-            occn[0] = own[0] ? sm.occ[lst[0]] : 0;
-            occn[1] = own[1] ? sm.occ[lst[1]] : 0;
-            max_occ = __builtin_amdgcn_readfirstlane(sm.occ[(p.SP + 3) & ~3]);
-        }
         const Row &x = v[g];
         const int t = tv[g];
         const bool live = t >= 0 && t < Tlive;
@@ -952,7 +964,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bool in = live && own[s];
-            const int off = (lst[s] < p.SP ? lst[s] : p.SP) * sm.TP + (t > 0 ? t : 0);   // a valid address, masked afterwards
+            const int off = crow[s] + (t > 0 ? t : 0);       // a valid address, masked afterwards
             const cell_t a = sm.al[off], bb = sm.be[off], e = sm.em[off];
             pr[s] = in ? a.x * bb.x * __builtin_amdgcn_rcpf(e.x) : 0.f;
             ks[s] = cell_k(a) + cell_k(bb) - cell_k(e);
@@ -984,7 +996,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         // (only lanes that own a state write; pass k adds the k-th repetition of a label)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            if (own[s] && occn[s] == 0) *gat[s] = z[s] * rinv;
+            if (first_occ[s]) *gat[s] = z[s] * rinv;
         for (int k = 1; k <= max_occ; ++k) {
             lds_order();
 #pragma unroll
@@ -994,7 +1006,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         lds_order();
         // dense rows: grad = softmax(x) * scale - occupancy   (dead rows: scale = occupancy = 0)
         if (t >= 0) {
-            float *gp = p.grad + ((int64_t)t * p.B + b) * p.C;
+            float *gp = grow[g];
             if (smooth) x.template store_grad<NT, true>(gp, trow, i16, rs[g] * (1.f - p.ls_b), col_ok, live ? -p.ls_b * gsc : 0.f);
             else x.template store_grad<NT, false>(gp, trow, i16, rs[g], col_ok, 0.f);
         }
