@@ -51,9 +51,15 @@ __device__ __forceinline__ void through_store(wt_f2 *p, wt_f2 v)
 {
     asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
+// (A vector-memory store of MORE than 64 bits reads its data registers over several cycles: a VALU instruction that
+// overwrites them must keep 2 wait states behind it on gfx940+ -- LLVM's hazard recognizer inserts them for stores it
+// knows, and knows nothing of an inline-asm one.  Without the s_nop a packed multiply-add scheduled right behind the store
+// changed the last component of the last lanes' data: wrong gradient values in columns 51, 55, 59, 63 of a row, found
+// when the order of the tile reads and the stores in R16Row::store_grad changed; the same hazard is behind the
+// "address-select" scatter variant of round 4 that gave wrong label-smoothed gradients.)
 __device__ __forceinline__ void through_store(wt_f4 *p, wt_f4 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 // gradient store of a launch: write-through while logits + gradient fit the memory-side cache, non-temporal
 // beyond it (r16 kernel, T = 150, C = 158, us per launch, write-through / non-temporal: B = 512 25.9 / 30.6,

@@ -451,9 +451,18 @@ struct R16Row {
     __device__ __forceinline__ void store_grad(float *g, const float *trow, int i16, float rs, bool col_ok, float cb) const
     {
         const f2_t r2 = {rs, rs}, cb2 = {cb, cb};
+        // every tile read first, then the arithmetic and the stores: a gradient store is inline asm with a memory clobber,
+        // and a tile read placed behind one waits for its own LDS round trip with nothing else in flight -- three round
+        // trips in a row per group
+        f4_t o4[N4 > 0 ? N4 : 1];
+        f2_t o2[N2 > 0 ? N2 : 1];
+#pragma unroll
+        for (int j = 0; j < N4; ++j) o4[j] = *reinterpret_cast<const f4_t *>(trow + off4(j, i16));
+#pragma unroll
+        for (int k = 0; k < N2; ++k) o2[k] = *reinterpret_cast<const f2_t *>(trow + off2(k, i16));
 #pragma unroll
         for (int j = 0; j < N4; ++j) {
-            const f4_t o = *reinterpret_cast<const f4_t *>(trow + off4(j, i16));
+            const f4_t o = o4[j];
             f2_t olo = {o.x, o.y}, ohi = {o.z, o.w};
             if (LS) { olo += cb2; ohi += cb2; }
             const f2_t xlo = {a[j].x, a[j].y}, xhi = {a[j].z, a[j].w};
@@ -463,7 +472,7 @@ struct R16Row {
         }
 #pragma unroll
         for (int k = 0; k < N2; ++k) {
-            f2_t o = *reinterpret_cast<const f2_t *>(trow + off2(k, i16));
+            f2_t o = o2[k];
             if (LS) o += cb2;
             const f2_t v = __builtin_elementwise_fma(c[k], r2, o);
             if (k < N2 - 1 || col_ok) grad_store<NT>(reinterpret_cast<f2_t *>(g + off2(k, i16)), v);
