@@ -945,6 +945,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         max_occ = __builtin_amdgcn_readfirstlane(sm.occ[(p.SP + 3) & ~3]);
     }
     const bool first_occ[2] = {own[0] && occn[0] == 0, own[1] && occn[1] == 0};
+    float *const sink = sm.dummy + 4;                        // (write-only)
 #pragma unroll
     for (int g = G - 1; g >= 0; --g) {
         if (!grp[g]) continue;
@@ -1003,9 +1004,11 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         }
         // MINUS the class occupancy of the four rows, scattered into the all-zero tile
         // (only lanes that own a state write; pass k adds the k-th repetition of a label)
+        // (through an address select, not under an exec mask: a predicated store costs the wave a compare, a mask
+        // save, the store and a mask restore -- one instruction at a time, scalar or vector; lanes without a state write
+        // a spare word)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            if (first_occ[s]) *gat[s] = z[s] * rinv;
+        for (int s = 0; s < 2; ++s) *(first_occ[s] ? gat[s] : sink) = z[s] * rinv;
         for (int k = 1; k <= max_occ; ++k) {
             lds_order();
 #pragma unroll
@@ -1023,8 +1026,7 @@ __global__ __launch_bounds__(kThreads, 4) void noblank_r16_kernel(NoblankParams 
         // the tile is all zeros again: the label slots, not three 16-byte stores per lane (an LDS store costs the wave
         // issue time by the byte: tools/micro/km_probe.hip)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            if (own[s]) *gat[s] = 0.f;
+        for (int s = 0; s < 2; ++s) *(own[s] ? gat[s] : sink) = 0.f;
         lds_order();
         CTC_R16_RELOAD(g);
     }
