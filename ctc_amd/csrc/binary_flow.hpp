@@ -247,7 +247,17 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
     const int lane_l = lane < p.SP ? lane : 0;
     const bool in_l = lane < L;
     const float ninf = -__builtin_inff();
-    auto rows_of = [&](int uu, int jg, int (&tt)[4], int (&tl)[4], int &t_hi, int &t_lo) {
+    // (a worker's OWN groups: the rows of every group are made once, before its gradient loop, and kept as opaque scalars --
+    // the chain of compares and selects below is ~45 scalar instructions, a wave issues one instruction at a time whatever
+    // its kind, and the gradient half is bound by issue; `own` selects the cached values)
+    int c_tt[kFlowGroups][4], c_tl[kFlowGroups][4], c_hi[kFlowGroups], c_lo[kFlowGroups];
+    auto rows_of = [&](int uu, int jg, int (&tt)[4], int (&tl)[4], int &t_hi, int &t_lo, bool own = false) {
+        if (own) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { tt[i] = c_tt[jg][i]; tl[i] = c_tl[jg][i]; }
+            t_hi = c_hi[jg]; t_lo = c_lo[jg];
+            return;
+        }
         t_hi = -1; t_lo = p.T;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -259,17 +269,17 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             }
         }
     };
-    auto post_ready = [&](int uu, int jg) -> bool {                  // have both scans passed the rows of the group?
+    auto post_ready = [&](int uu, int jg, bool own = false) -> bool {   // have both scans passed the rows of the group?
         int tt[4], tl[4], t_hi, t_lo;
-        rows_of(uu, jg, tt, tl, t_hi, t_lo);
+        rows_of(uu, jg, tt, tl, t_hi, t_lo, own);
         if (t_hi < 0) return true;
         const int pa = *(lds_cvint *)sm.prog, pb = *(lds_cvint *)(sm.prog + 1), bad = *(lds_cvint *)sm.fail;
         if (bad) starved = true;
         return bad || (pa >= t_hi + 1 && pb >= Tb - t_lo);
     };
-    auto post = [&](int uu, int jg) {
+    auto post = [&](int uu, int jg, bool own = false) {
         int tt[4], tl[4], t_hi, t_lo;
-        rows_of(uu, jg, tt, tl, t_hi, t_lo);
+        rows_of(uu, jg, tt, tl, t_hi, t_lo, own);
         if (t_hi < 0) return;                                // (uniform) no live row
         lds_order();
         if (p.SP <= 32) {                                    // (uniform) two rows per register, side by side in the halves of the wave:
@@ -358,9 +368,9 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
                     p.gamma[((int64_t)b * p.T + tl[k]) * p.S + lane] = starved ? __builtin_nanf("") : pe[k] * __builtin_amdgcn_rcpf(sum[k]);
         }
     };
-    auto elem = [&](int uu, int jg, unsigned slow4, auto &&P) {   // slow4: the careful-path bits of the group's four slots; P(r, side, j): their sigmoids
+    auto elem = [&](int uu, int jg, unsigned slow4, auto &&P, bool own = false) {   // slow4: the careful-path bits of the group's four slots; P(r, side, j): their sigmoids
         int tt[4], tl[4], t_hi, t_lo;
-        rows_of(uu, jg, tt, tl, t_hi, t_lo);
+        rows_of(uu, jg, tt, tl, t_hi, t_lo, own);
         if (starved) raise_status(p.counter, kStatusBinaryStarved);
         if constexpr (GAMMA) {                               // posteriors only: rows beyond T_b get zeros, no gradient
 #pragma unroll
@@ -782,12 +792,19 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             for (int side = 0; side < 2; ++side)
 #pragma unroll
                 for (int j = 0; j < CH; ++j) v[g][side][j] = __builtin_amdgcn_rcpf(v[g][side][j]);
+#pragma unroll
+    for (int jg = 0; jg < kFlowGroups; ++jg) {
+        rows_of(u, jg, c_tt[jg], c_tl[jg], c_hi[jg], c_lo[jg]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c_tt[jg][i] = opaque_s(c_tt[jg][i]); c_tl[jg][i] = opaque_s(c_tl[jg][i]); }
+        c_hi[jg] = opaque_s(c_hi[jg]); c_lo[jg] = opaque_s(c_lo[jg]);
+    }
     stamp(p, 3);
 #pragma unroll
     for (int jg = kFlowGroups - 1; jg >= 0; --jg) {          // rows nearest the middle are ready first
         if (jg < NGR && !(jg == 0 && delegated)) {           // (uniform)
             int spins = 0;
-            while (!starved && !post_ready(u, jg)) {
+            while (!starved && !post_ready(u, jg, true)) {
                 if (++spins >= (1 << 20)) starved = true;
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -797,8 +814,8 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             else if (jg == 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
 #endif
-            post(u, jg);
-            elem(u, jg, (slow >> (4 * jg)) & 15u, [&](int r, int side, int j) { return v[2 * jg + r][side][j]; });
+            post(u, jg, true);
+            elem(u, jg, (slow >> (4 * jg)) & 15u, [&](int r, int side, int j) { return v[2 * jg + r][side][j]; }, true);
         }
     }
     stamp(p, 7);
