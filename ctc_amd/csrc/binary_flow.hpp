@@ -251,6 +251,8 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
     // the chain of compares and selects below is ~45 scalar instructions, a wave issues one instruction at a time whatever
     // its kind, and the gradient half is bound by issue; `own` selects the cached values)
     int c_tt[kFlowGroups][4], c_tl[kFlowGroups][4], c_hi[kFlowGroups], c_lo[kFlowGroups];
+    int c_ro[kFlowGroups][4];                                // max(tl, 0) * SP: the lattice row of a live slot (row 0 for an idle one)
+    auto row_off = [&](int jg, int i, int tl_i, bool own) { return own ? c_ro[jg][i] : (tl_i >= 0 ? tl_i : 0) * p.SP; };
     auto rows_of = [&](int uu, int jg, int (&tt)[4], int (&tl)[4], int &t_hi, int &t_lo, bool own = false) {
         if (own) {
 #pragma unroll
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 tr[r] = up ? tl[2 * r + 1] : tl[2 * r];
-                const int off = (tr[r] >= 0 ? tr[r] : 0) * p.SP + (hl < p.SP ? hl : 0);
+                const int off = (up ? row_off(jg, 2 * r + 1, tl[2 * r + 1], own) : row_off(jg, 2 * r, tl[2 * r], own)) + (hl < p.SP ? hl : 0);
                 const float za = sm.al[off], zb = sm.be[off], ze = sm.em[off];
                 z[r] = (in_h && tr[r] >= 0) ? za + zb - ze : ninf;
             }
@@ -320,7 +322,8 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const float inv = __builtin_amdgcn_rcpf(sum[r]);
-                if (hl < p.SP && tr[r] >= 0) sm.be[tr[r] * p.SP + hl] = pe[r] * (gs * inv);
+                if (hl < p.SP && tr[r] >= 0)
+                    sm.be[(up ? row_off(jg, 2 * r + 1, tl[2 * r + 1], own) : row_off(jg, 2 * r, tl[2 * r], own)) + hl] = pe[r] * (gs * inv);
                 if (GAMMA && hl < p.S && tr[r] >= 0)         // posteriors output: gamma_t(l), rows sum to 1
                     p.gamma[((int64_t)b * p.T + tr[r]) * p.S + hl] = starved ? __builtin_nanf("") : pe[r] * inv;
             }
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
             float za[4], zb[4], ze[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int off = (tl[k] >= 0 ? tl[k] : 0) * p.SP + lane_l;
+                const int off = row_off(jg, k, tl[k], own) + lane_l;
                 za[k] = sm.al[off]; zb[k] = sm.be[off]; ze[k] = sm.em[off];
             }
 #pragma unroll
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
         if (lane < p.SP) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (tl[k] >= 0) sm.be[tl[k] * p.SP + lane] = pe[k] * (gs * __builtin_amdgcn_rcpf(sum[k]));
+                if (tl[k] >= 0) sm.be[row_off(jg, k, tl[k], own) + lane] = pe[k] * (gs * __builtin_amdgcn_rcpf(sum[k]));
         }
         if (GAMMA && lane < p.S) {                           // posteriors output: gamma_t(l), rows sum to 1
 #pragma unroll
@@ -798,6 +801,8 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
 #pragma unroll
         for (int i = 0; i < 4; ++i) { c_tt[jg][i] = opaque_s(c_tt[jg][i]); c_tl[jg][i] = opaque_s(c_tl[jg][i]); }
         c_hi[jg] = opaque_s(c_hi[jg]); c_lo[jg] = opaque_s(c_lo[jg]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c_ro[jg][i] = opaque_s((c_tl[jg][i] >= 0 ? c_tl[jg][i] : 0) * p.SP);
     }
     stamp(p, 3);
 #pragma unroll
