@@ -657,6 +657,13 @@ __device__ __forceinline__ void bin_store_at(float *row, unsigned voff, float v)
     else asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" ::"v"(voff), "v"(v), "s"(row), "n"(OFF) : "memory");
 }
 
+// The row base of the stores above is an "s" operand of an inline-asm vector-memory instruction: if the compiler has just
+// RELOADED it from a spill lane (v_readlane: a VALU write of an SGPR), the instruction needs 5 wait states behind that
+// write, and the compiler pads them only for instructions it knows.  (Seen in round 4: a variant that kept the row bases in
+// spilled scalars faulted.)  One statement per row, in front of its first store: it takes the base as an input, so any
+// reload sits in front of it.
+__device__ __forceinline__ void bin_row_base_settled(const float *row) { asm volatile("s_nop 4" ::"s"(row)); }
+
 template <bool WT>
 __device__ __forceinline__ void bin_store_col(float *row, unsigned voff, int j, float v)
 {   // (j is a constant once the caller's loop is unrolled)
@@ -1039,6 +1046,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_pipe_kernel(BinaryParams p
         for (int i = 0; i < 4; ++i) {
             if (tt[i] < 0) continue;                         // wave-uniform
             float *g = p.grad + ((int64_t)tt[i] * p.B + b) * p.C;
+            bin_row_base_settled(g);
             const int slot = 2 * (2 * jg + (i & 1)) + (i >> 1);
             if (tl[i] < 0 || starved) {                      // (uniform) dead row: zeros; starved: NaN
                 const float fill = starved ? __builtin_nanf("") : 0.f;

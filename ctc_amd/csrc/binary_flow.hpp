@@ -422,6 +422,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float *g = p.grad + ((int64_t)tl[i] * p.B + b) * p.C;
+                bin_row_base_settled(g);
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const float pr = P(i & 1, i >> 1, j);
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_flow_kernel(BinaryParams p
         for (int i = 0; i < 4; ++i) {
             if (tt[i] < 0) continue;                         // wave-uniform
             float *g = p.grad + ((int64_t)tt[i] * p.B + b) * p.C;
+            bin_row_base_settled(g);
             const int slot = 2 * (i & 1) + (i >> 1);         // (bit of slow4: slots (2jg, 0), (2jg, 1), (2jg+1, 0), (2jg+1, 1))
             if (tl[i] < 0 || starved) {                      // (uniform) dead row: zeros; starved: NaN
                 const float fill = starved ? __builtin_nanf("") : 0.f;
