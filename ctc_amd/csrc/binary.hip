@@ -659,9 +659,8 @@ __device__ __forceinline__ void bin_store_at(float *row, unsigned voff, float v)
 
 // The row base of the stores above is an "s" operand of an inline-asm vector-memory instruction: if the compiler has just
 // RELOADED it from a spill lane (v_readlane: a VALU write of an SGPR), the instruction needs 5 wait states behind that
-// write, and the compiler pads them only for instructions it knows.  (Seen in round 4: a variant that kept the row bases in
-// spilled scalars faulted.)  One statement per row, in front of its first store: it takes the base as an input, so any
-// reload sits in front of it.
+// write, and the compiler pads them only for instructions it knows (/opt/skills/guides/cdna_hip_programming.md 5.7).  One
+// statement per row, in front of its first store: it takes the base as an input, so any reload sits in front of it.
 __device__ __forceinline__ void bin_row_base_settled(const float *row) { asm volatile("s_nop 4" ::"s"(row)); }
 
 template <bool WT>
