@@ -628,11 +628,13 @@ def test_noblank_more_samples_than_cus(dev):
     assert_close(r, ref, 2e-7)
 
 
-def test_autograd_path_is_graph_capturable(dev):
+@pytest.mark.parametrize("B", [8, 600])
+def test_autograd_path_is_graph_capturable(dev, B):
     """the C ABI only enqueues work (no allocation, no host sync): forward + backward can be
-    captured into a hipGraph and replayed on new data in the same buffers"""
+    captured into a hipGraph and replayed on new data in the same buffers (B = 8: the one-sample-per-workgroup launch;
+    B = 600: the persistent form, replayed twice -- nothing of a launch's state may survive it)"""
     import ctc_amd
-    x, lab, Tb, L = synth_noblank(5, 30, 8, 20, 6, var_T=True)
+    x, lab, Tb, L = synth_noblank(5, 30, B, 20, 6, var_T=True)
     xs = x.to(dev).requires_grad_(True)
     labd, Tbd, Ld = lab.to(dev), Tb.to(dev), L.to(dev)
     s = torch.cuda.Stream()
@@ -648,14 +650,15 @@ def test_autograd_path_is_graph_capturable(dev):
     with torch.cuda.graph(g):
         loss = ctc_amd.CTCLoss.apply(xs, labd, Tbd, Ld)
         loss.backward()
-    x2, _, _, _ = synth_noblank(6, 30, 8, 20, 6)
-    with torch.no_grad():
-        xs.copy_(x2.to(dev))
-    g.replay()
-    torch.cuda.synchronize()
-    ref = ctc_numpy.noblank_ctc(np_(x2), np_(lab), np_(Tb), np_(L), np.float64)
-    assert abs(float(loss.detach()) - float(ref["loss"])) < 1e-4 * max(1.0, abs(float(ref["loss"])))
-    assert np.abs(np_(xs.grad) - ref["grad"]).max() < 2e-6 * 32
+    for seed in (6, 7):
+        x2, _, _, _ = synth_noblank(seed, 30, B, 20, 6)
+        with torch.no_grad():
+            xs.copy_(x2.to(dev))
+        g.replay()
+        torch.cuda.synchronize()
+        ref = ctc_numpy.noblank_ctc(np_(x2), np_(lab), np_(Tb), np_(L), np.float64)
+        assert abs(float(loss.detach()) - float(ref["loss"])) < 1e-4 * max(1.0, abs(float(ref["loss"])))
+        assert np.abs(np_(xs.grad) - ref["grad"]).max() < 2e-6 * 32 * 8 / B
 
 
 @pytest.mark.parametrize("shape", [(20, 4, 10, 5), (150, 8, 158, 20), (40, 3, 300, 70), (168, 5, 64, 31), (61, 300, 34, 9),
